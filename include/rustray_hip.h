@@ -1,0 +1,299 @@
+/*
+ * rustray_hip.h — C ABI of the MI355X trace-loop replacement for rustray.
+ *
+ * This is the drop-in boundary for ONE path of the reference: the per-pixel /
+ * per-sample trace loop that `RendererManager::start` spawns
+ * (reference src/renderer.rs:105-172, worker body :267-315) and that calls
+ * `Raytracing::render(x, y) -> PixelData` (reference src/raytracing.rs:275-427).
+ * One `rr_render*` call replaces that whole cell-queue + thread-pool frame and
+ * fills the four buffers `Run::apply_pixels` fills today
+ * (reference src/run.rs:519-541: image RGBA8, normals, depth, objects).
+ *
+ * The reference has no FFI; its `Scene` is made of Rust trait objects
+ * (src/scene.rs:69-83, src/shape/mod.rs:14-46).  The boundary therefore takes
+ * a *flat scene*: plain arrays that a small host-side shim fills by walking
+ * `Scene` (see INTEGRATION.md for the Rust shim).  Every struct below is POD,
+ * little-endian, naturally aligned; all matrices are column-major 4x4 f32 as
+ * nalgebra stores them.
+ *
+ * Ownership: the caller owns every input and output buffer.  The library
+ * copies what it needs during rr_scene_create and owns only its handle and
+ * device memory.  Nothing here calls back into the host.  No function aborts
+ * or throws across the ABI: every entry point returns RR_OK (0) or a negative
+ * rr_status, and rr_last_error() returns a thread-local message.
+ */
+#ifndef RUSTRAY_HIP_H
+#define RUSTRAY_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RR_ABI_VERSION 1u
+
+typedef enum rr_status {
+    RR_OK = 0,
+    RR_ERR_INVALID_ARGUMENT = -1,  /* NULL pointer, bad index, bad size */
+    RR_ERR_UNSUPPORTED = -2,       /* e.g. max_recursion above RR_MAX_RECURSION */
+    RR_ERR_NO_DEVICE = -3,         /* no HIP device / HIP runtime failure at init */
+    RR_ERR_DEVICE = -4,            /* a HIP call failed during the frame */
+    RR_ERR_OUT_OF_MEMORY = -5,
+    RR_ERR_CANCELLED = -6          /* *cancel became non-zero during the frame */
+} rr_status;
+
+/* Largest RaytracingConfig::max_recursion the device path accepts
+ * (reference default is 6, src/raytracing.rs:124). */
+#define RR_MAX_RECURSION 16u
+
+/* TextureType order of reference src/shape/mod.rs:633-643. */
+enum {
+    RR_TEX_BASE = 0,
+    RR_TEX_AMBIENT_EMISSIVE = 1,
+    RR_TEX_SPECULAR = 2,
+    RR_TEX_NORMAL = 3,
+    RR_TEX_ALPHA = 4,
+    RR_TEX_ROUGHNESS = 5,
+    RR_TEX_AMBIENT_OCCLUSION = 6,
+    RR_TEX_REFLECTIVITY = 7,
+    RR_TEX_COUNT = 8
+};
+
+/* One decoded image (image::DynamicImage after `.to_rgba()`,
+ * reference src/shape/mod.rs:531, :586-589).  Row-major, top row first. */
+typedef struct rr_texture {
+    uint32_t width;
+    uint32_t height;
+    const uint8_t* rgba8; /* width*height*4 bytes */
+} rr_texture;
+
+/* All fields of `Material` that the trace loop reads
+ * (reference src/shape/mod.rs:95-134; defaults :138-180). */
+typedef struct rr_material {
+    float ambient_color[3];
+    float base_color[3];
+    float specular_color[3];
+    float alpha;
+    float shininess;
+    float reflectivity;
+    float refraction_index;
+    float normal_map_strength;
+    float shadow_softness;
+    float roughness;
+    int32_t texture[RR_TEX_COUNT]; /* index into rr_flat_scene.textures, or -1 */
+    uint8_t texture_filtering_nearest;
+    uint8_t cast_shadow;
+    uint8_t receive_shadow;
+    uint8_t monte_carlo;
+    uint8_t smooth_shading;
+    uint8_t reflection_only;
+    uint8_t backface_cullig; /* sic: the reference's field name */
+    uint8_t _pad;
+} rr_material;
+
+/* Triangle mesh data of `Mesh` (reference src/shape/mesh.rs:10-21).  Meshes
+ * are shared: several items may name the same mesh (instancing). */
+typedef struct rr_mesh {
+    const float* positions;         /* n_vertices * 3 */
+    const uint32_t* indices;        /* n_triangles * 3 */
+    const float* uvs;               /* n_uvs * 2, may be NULL */
+    const uint32_t* uv_indices;     /* n_uv_faces * 3, may be NULL */
+    const float* normals;           /* n_normals * 3, may be NULL */
+    const uint32_t* normal_indices; /* n_normal_faces * 3, may be NULL */
+    uint32_t n_vertices;
+    uint32_t n_triangles;
+    uint32_t n_uvs;
+    uint32_t n_uv_faces;
+    uint32_t n_normals;
+    uint32_t n_normal_faces;
+} rr_mesh;
+
+enum { RR_ITEM_SPHERE = 0, RR_ITEM_MESH = 1 };
+
+/* One scene item: `ShapeBasics` (reference src/shape/mod.rs:661-680) plus
+ * the shape payload.  Item ORDER is semantically significant
+ * (reference src/raytracing.rs:440-487) and must be Scene.items order. */
+typedef struct rr_item {
+    uint32_t kind;          /* RR_ITEM_SPHERE | RR_ITEM_MESH */
+    uint32_t id;            /* ShapeBasics::id, reported as object_id */
+    int32_t material;       /* `get_material()`: full material, textures included */
+    int32_t material_cache; /* `get_material_cache_without_textures()`
+                               (reference src/shape/mod.rs:769-772): must have every
+                               texture slot = -1 */
+    int32_t mesh;           /* index into meshes (kind == mesh), else -1 */
+    float radius;           /* Ball radius (kind == sphere) */
+    float trans[16];        /* ShapeBasics::trans, column-major */
+    float trans_inv[16];    /* ShapeBasics::tran_inverse, column-major */
+    float bbox_min[3];      /* ShapeBasics::b_box in LOCAL space */
+    float bbox_max[3];
+    uint8_t visible;
+    uint8_t flip_normals;
+    uint8_t _pad[2];
+} rr_item;
+
+enum { RR_LIGHT_DIRECTIONAL = 0, RR_LIGHT_POINT = 1, RR_LIGHT_SPOT = 2 };
+
+/* `Light` (reference src/scene.rs:40-51). */
+typedef struct rr_light {
+    float pos[3];
+    float dir[3];
+    float color[3];
+    float intensity;
+    float max_angle; /* radians */
+    uint32_t light_type;
+    uint8_t enabled;
+    uint8_t _pad[3];
+} rr_light;
+
+typedef struct rr_flat_scene {
+    uint32_t abi_version; /* RR_ABI_VERSION */
+    uint32_t n_items;
+    uint32_t n_meshes;
+    uint32_t n_materials;
+    uint32_t n_textures;
+    uint32_t n_lights;
+    const rr_item* items;
+    const rr_mesh* meshes;
+    const rr_material* materials;
+    const rr_texture* textures;
+    const rr_light* lights;
+} rr_flat_scene;
+
+/* What the trace loop reads of `Camera` (reference src/camera.rs:19-40,
+ * used at src/raytracing.rs:282-283, :340, :349, :355-356, :369-393). */
+typedef struct rr_camera {
+    uint32_t width;
+    uint32_t height;
+    float projection_inverse[16];
+    float view_inverse[16];
+} rr_camera;
+
+/* `RaytracingConfig` by value (reference src/raytracing.rs:92-106) plus the
+ * seed of the counter-based RNG that replaces the reference's un-seeded
+ * `rand::thread_rng()` in `jitter` (src/raytracing.rs:616-618).  Pass the
+ * EFFECTIVE config: JSON `config` blocks override the CLI in the reference
+ * (src/scene.rs:180-198). */
+typedef struct rr_config {
+    uint64_t seed;
+    float focal_length;
+    float aperture_size;
+    float fog_density;
+    float fog_color[3];
+    uint16_t samples;
+    uint16_t max_recursion;
+    uint8_t monte_carlo;
+    uint8_t gamma_correction;
+    uint8_t _pad[2];
+} rr_config;
+
+/* Output of one frame = what `Run::apply_pixels` stores per PixelData
+ * (reference src/run.rs:519-541, PixelData src/raytracing.rs:57-70).
+ * rgba8 is required; the aux pointers may be NULL.  All are row-major with
+ * `width` pixels per row, y = 0 at the top. */
+typedef struct rr_frame {
+    uint8_t* rgba8;      /* w*h*4, alpha forced to 255 (src/run.rs:527) */
+    float* normal;       /* w*h*3 */
+    float* depth;        /* w*h */
+    uint32_t* object_id; /* w*h */
+} rr_frame;
+
+/* A subset of the frame for one rank of a multi-GPU render.  The frame is cut
+ * into tiles of tile_w x tile_h pixels, numbered row-major; this rank owns the
+ * tiles with (tile_index % n_ranks == rank).  The rank's pixels are written
+ * COMPACTLY, in tile order then row-major inside the tile (clipped at the
+ * frame border), into buffers of rr_region_pixel_count() pixels.
+ * n_ranks = 1, rank = 0 selects the whole frame (still in tile order). */
+typedef struct rr_region {
+    uint32_t tile_w;
+    uint32_t tile_h;
+    uint32_t n_ranks;
+    uint32_t rank;
+} rr_region;
+
+/* Result of rr_pick (reference Raytracing::pick, src/raytracing.rs:237-273). */
+typedef struct rr_pick_result {
+    uint32_t hit;       /* 0 = None */
+    uint32_t object_id; /* ShapeBasics::id */
+    uint32_t item_index;
+    float distance;
+} rr_pick_result;
+
+/* Per-frame work counters: one "ray" = one Raytracing::trace
+ * call (reference src/raytracing.rs:429). */
+typedef struct rr_frame_stats {
+    uint64_t primary_rays;
+    uint64_t secondary_rays; /* reflection + refraction */
+    uint64_t shadow_rays;
+    uint64_t shaded_hits;
+    double ms_total;        /* device time of the whole frame */
+    double ms_trace_closest;
+    double ms_trace_shadow;
+    double ms_shade;
+    uint64_t launches_trace_closest;
+    uint64_t launches_trace_shadow;
+    uint64_t launches_shade;
+} rr_frame_stats;
+
+typedef struct rr_scene rr_scene; /* opaque */
+
+/* Number of HIP devices visible; 0 if none (never fails). */
+int rr_device_count(void);
+
+/* Thread-local description of the last failure on this thread ("" if none). */
+const char* rr_last_error(void);
+
+/* Validate and upload a flat scene to `device`; build the acceleration
+ * structures (replaces Scene::update's BVH build, reference
+ * src/scene.rs:1674-1688, and parry's per-TriMesh Qbvh, src/shape/mesh.rs:171). */
+int rr_scene_create(const rr_flat_scene* scene, int device, rr_scene** out);
+void rr_scene_destroy(rr_scene* scene);
+
+/* Replace item transforms in place (animation / GUI edits between frames:
+ * reference ShapeBasics::apply_mat, src/shape/mod.rs:748-753; Scene::apply_frame
+ * src/scene.rs:1695-1713).  trans / trans_inv hold n_items * 16 floats. */
+int rr_scene_update_transforms(rr_scene* scene, const float* trans, const float* trans_inv);
+
+/* The reference's per-pixel sub-sample table (src/raytracing.rs:290-313):
+ * cell_size^2 cells shuffled with StdRng::seed_from_u64(0), truncated to
+ * `samples`.  Writes samples*2 uint16 (x_i, y_i) and *cell_size. */
+int rr_sample_table(uint16_t samples, uint16_t* xy_out, uint32_t* cell_size_out);
+
+/* Render one whole frame into HOST buffers (synchronous).
+ * sample_xy: samples*2 uint16 from the host's own rand, or NULL for the
+ * built-in table.  cancel: optional flag polled between device launches. */
+int rr_render(rr_scene* scene, const rr_camera* camera, const rr_config* config,
+              const uint16_t* sample_xy, const rr_frame* out, const volatile int* cancel);
+
+/* Number of pixels `region` owns in a width x height frame. */
+uint64_t rr_region_pixel_count(uint32_t width, uint32_t height, const rr_region* region);
+
+/* Render `region` of the frame into DEVICE buffers (HIP device pointers on the
+ * scene's device) holding rr_region_pixel_count() pixels, compact, in region
+ * order.  Work is enqueued on `hip_stream` (a hipStream_t, NULL = the default
+ * stream); the call returns once everything is enqueued or, when the frame
+ * needs more than one batch of samples, after the last batch has been
+ * enqueued (earlier batches are awaited).  The caller synchronises the stream. */
+int rr_render_region_device(rr_scene* scene, const rr_camera* camera, const rr_config* config,
+                            const uint16_t* sample_xy, const rr_region* region,
+                            const rr_frame* out_device, void* hip_stream,
+                            const volatile int* cancel);
+
+/* Scatter a compact region buffer back to full-frame layout, on device.
+ * Used by rank 0 after the gather; src holds the concatenated per-rank
+ * compact buffers in rank order. elem_bytes = bytes per pixel (4, 12, 4, 4). */
+int rr_deinterleave_device(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h,
+                           uint32_t n_ranks, uint32_t elem_bytes, const void* src_device,
+                           void* dst_device, int device, void* hip_stream);
+
+/* Single-ray query at the pixel centre (reference src/raytracing.rs:237-273). */
+int rr_pick(rr_scene* scene, const rr_camera* camera, int x, int y, rr_pick_result* out);
+
+/* Counters and device timings of the most recent frame on this scene. */
+int rr_scene_last_stats(const rr_scene* scene, rr_frame_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUSTRAY_HIP_H */

@@ -1,0 +1,1288 @@
+// oracle.cpp — TEST INFRASTRUCTURE: CPU restatement of rustray's trace loop.
+//
+// This file is the parity oracle and the CPU baseline of this repository.  It
+// is NOT product code: only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg may load it.  The product (rustray_amd/) never links,
+// imports or calls anything in oracle/.
+//
+// What it restates (reference = Bastl34/rustray, paths relative to its root):
+//   src/raytracing.rs:275-998   render, trace, shading recursion, jitter, fresnel,
+//                               reflection/transmission, texture lookups
+//   src/shape/mod.rs:510-629    nearest / bilinear texel fetch
+//   src/shape/mod.rs:755-761    get_inverse_ray
+//   src/shape/mesh.rs:51-161,204-259   mesh bbox / intersect / uv / smooth normal
+//   src/shape/sphere.rs:45-99   sphere bbox / intersect / uv
+//   src/helper.rs:11-20,35-49   approx_equal, interpolate
+// Third-party arithmetic that is NOT in the reference tree (no Cargo.lock, crates
+// un-vendored) is restated from the crates' published algorithms and marked
+// [recalled]:  parry3d 0.13 (ray/AABB, ray/triangle, ray/ball),
+// rand 0.8 (StdRng = ChaCha12, seed_from_u64, shuffle, Uniform<f32>),
+// nalgebra 0.32 (dot / cross / normalize / mat*vec evaluation order).
+//
+// PARITY STATUS: "parity unpinned" against the real Rust binary — the reference
+// ships no tests, golden vectors or fixtures for this path and
+// cannot be built offline.  The restatement is pinned only by (a) published
+// known-answer vectors for the primitives it borrows (ChaCha, Philox) and
+// (b) hand-derived unit cases in tests/.
+//
+// Declared divergences from the reference (all documented in DESIGN.md):
+//   D1  jitter() draws come from a counter-based Philox4x32-10 keyed on
+//       (seed, pixel, sample, path node, stream) instead of rand::thread_rng()
+//       (reference src/raytracing.rs:616-618 is un-seeded).
+//   D2  sin/cos/acos/atan2 are the fixed Cephes sequences of oracle_math.h.
+//   D3  NaN bbox distances are treated as a miss instead of panicking
+//       (reference src/raytracing.rs:466 `partial_cmp().unwrap()`).
+//   D4  Triangle ties (bit-equal toi inside one mesh) go to the lowest face index;
+//       parry's Qbvh order is build-dependent.  Scene-BVH candidate order
+//       (src/scene.rs:1715-1722) is taken as Scene.items order.
+//   D5  The per-pixel sub-sample table is an input (it is identical for every
+//       pixel in the reference, src/raytracing.rs:309).
+#include "../include/rustray_hip.h"
+#include "oracle_math.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+using namespace rro;
+
+// ---------------------------------------------------------------------------
+// small vector algebra, evaluation order as nalgebra 0.32 [recalled]
+// ---------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+struct V4 { float x, y, z, w; };
+struct V2 { float x, y; };
+
+static inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+static inline V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+static inline V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+static inline V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+static inline V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+static inline V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
+static inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline V3 cross(V3 a, V3 b) {
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+static inline float norm(V3 a) { return std::sqrt(dot(a, a)); }
+static inline V3 normalize(V3 a) { return a / norm(a); } // nalgebra: unscale by norm
+
+// column-major 4x4 times (x,y,z,w): column axpy order of nalgebra's gemv [recalled]
+static inline V4 mat_mul(const float* m, float x, float y, float z, float w) {
+    V4 r;
+    r.x = ((m[0] * x + m[4] * y) + m[8] * z) + m[12] * w;
+    r.y = ((m[1] * x + m[5] * y) + m[9] * z) + m[13] * w;
+    r.z = ((m[2] * x + m[6] * y) + m[10] * z) + m[14] * w;
+    r.w = ((m[3] * x + m[7] * y) + m[11] * z) + m[15] * w;
+    return r;
+}
+// Point3::from_homogeneous: divide by w (reference uses it at shape/mod.rs:760)
+static inline V3 point_from_h(V4 v) { return V3{v.x / v.w, v.y / v.w, v.z / v.w}; }
+
+struct Ray { V3 origin, dir; };
+
+// reference src/helper.rs:11-20
+static inline bool approx_equal(float a, float b) {
+    const float factor = 1000000.0f; // 10f32.powi(6)
+    float ta = std::trunc(a * factor);
+    float tb = std::trunc(b * factor);
+    return ta == tb;
+}
+// reference src/helper.rs:35-38
+static inline float interpolate(float a, float b, float f) { return a + f * (b - a); }
+
+// ---------------------------------------------------------------------------
+// work counters
+// ---------------------------------------------------------------------------
+extern "C" {
+typedef struct rro_counters {
+    uint64_t rays_primary, rays_secondary, rays_shadow;
+    // [0] = closest-hit rays (primary+secondary), [1] = shadow rays
+    uint64_t nodes[2];      // BVH2 inner nodes fetched (64 B each)
+    uint64_t leaf_prims[2]; // triangles / spheres tested
+    uint64_t items[2];      // instance records fetched (bbox test + intersect)
+    uint64_t shaded_hits;
+    uint64_t texels;
+} rro_counters;
+}
+
+static thread_local rro_counters* tl_cnt = nullptr;
+static thread_local int tl_kind = 0; // 0 closest, 1 shadow
+#define CNT(field, n) do { if (tl_cnt) tl_cnt->field += (n); } while (0)
+
+// ---------------------------------------------------------------------------
+// parry3d 0.13 primitives [recalled]
+// ---------------------------------------------------------------------------
+// Aabb::cast_local_ray(ray, max_toi = f32::MAX, solid)  (parry3d query/ray/ray_aabb.rs)
+static bool aabb_cast_local_ray(const float* mins, const float* maxs, const Ray& ray, bool solid, float* toi) {
+    float tmin = 0.0f;
+    float tmax = 3.40282347e+38f;
+    const float o[3] = {ray.origin.x, ray.origin.y, ray.origin.z};
+    const float d[3] = {ray.dir.x, ray.dir.y, ray.dir.z};
+    for (int i = 0; i < 3; i++) {
+        if (d[i] == 0.0f) {
+            if (o[i] < mins[i] || o[i] > maxs[i]) return false;
+        } else {
+            float denom = 1.0f / d[i];
+            float inter_near = (mins[i] - o[i]) * denom;
+            float inter_far = (maxs[i] - o[i]) * denom;
+            if (inter_near > inter_far) { float t = inter_near; inter_near = inter_far; inter_far = t; }
+            tmin = rs_max(tmin, inter_near);
+            tmax = rs_min(tmax, inter_far);
+            if (tmin > tmax) return false;
+        }
+    }
+    *toi = (tmin == 0.0f && !solid) ? tmax : tmin;
+    return true;
+}
+
+// local_ray_intersection_with_triangle (parry3d query/ray/ray_triangle.rs).
+// Two-sided; returns toi, un-normalised oriented normal selector `back`.
+struct TriHit { float toi; V3 normal; int back; };
+static bool ray_triangle(V3 a, V3 b, V3 c, const Ray& ray, TriHit* out) {
+    V3 ab = b - a;
+    V3 ac = c - a;
+    V3 n = cross(ab, ac);
+    float d = dot(n, ray.dir);
+    if (d == 0.0f) return false;
+    V3 ap = ray.origin - a;
+    float t = dot(ap, n);
+    if ((t < 0.0f && d < 0.0f) || (t > 0.0f && d > 0.0f)) return false;
+    int fid = (d < 0.0f) ? 0 : 1;
+    d = rs_abs(d);
+    V3 e = -cross(ray.dir, ap);
+    float v, w, toi;
+    V3 normal;
+    if (t < 0.0f) {
+        v = -dot(ac, e);
+        if (v < 0.0f || v > d) return false;
+        w = dot(ab, e);
+        if (w < 0.0f || v + w > d) return false;
+        float invd = 1.0f / d;
+        toi = -t * invd;
+        normal = -normalize(n);
+    } else {
+        v = dot(ac, e);
+        if (v < 0.0f || v > d) return false;
+        w = -dot(ab, e);
+        if (w < 0.0f || v + w > d) return false;
+        float invd = 1.0f / d;
+        toi = t * invd;
+        normal = normalize(n);
+    }
+    if (!(toi <= 3.40282347e+38f)) return false; // Triangle::cast_local_ray_and_get_normal: toi <= max_toi
+    out->toi = toi;
+    out->normal = normal;
+    out->back = fid;
+    return true;
+}
+
+// ray_toi_with_ball + Ball::cast_local_ray_and_get_normal (parry3d query/ray/ray_ball.rs)
+static bool ray_ball(float radius, const Ray& ray, bool solid, float* toi_out, V3* normal_out) {
+    V3 dcenter = ray.origin; // centre is the local origin
+    float a = dot(ray.dir, ray.dir);
+    float b = dot(dcenter, ray.dir);
+    float c = dot(dcenter, dcenter) - radius * radius;
+    bool inside;
+    float toi;
+    if (a == 0.0f) {
+        if (c > 0.0f) return false;
+        inside = true; toi = 0.0f;
+    } else if (c > 0.0f && b > 0.0f) {
+        return false;
+    } else {
+        float delta = b * b - a * c;
+        if (delta < 0.0f) return false;
+        float t = (-b - std::sqrt(delta)) / a;
+        if (t <= 0.0f) {
+            inside = true;
+            toi = solid ? 0.0f : (-b + std::sqrt(delta)) / a;
+        } else {
+            inside = false; toi = t;
+        }
+    }
+    if (toi > 3.40282347e+38f) return false;
+    V3 pos = ray.origin + ray.dir * toi;
+    V3 n = normalize(pos);
+    *toi_out = toi;
+    *normal_out = inside ? -n : n;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// per-mesh acceleration structure (stands in for parry's Qbvh inside TriMesh,
+// reference src/shape/mesh.rs:67,171).  Binned-SAH BVH2; traversal is
+// exhaustive up to culling against the best toi, so the result equals the
+// brute-force minimum (tests check this property).
+// ---------------------------------------------------------------------------
+struct BNode {
+    float lo[2][3], hi[2][3]; // child boxes
+    int32_t child[2];         // >= 0 inner node index; < 0 leaf: ~(first | count-1 << 28)
+};
+struct MeshAccel {
+    std::vector<BNode> nodes;      // empty => single leaf
+    std::vector<uint32_t> order;   // triangle ids in leaf order
+    int32_t root;                  // node index or leaf code
+};
+
+struct BuildTri { float lo[3], hi[3], c[3]; uint32_t id; };
+
+static inline int32_t leaf_code(uint32_t first, uint32_t count) {
+    return ~(int32_t)(first | ((count - 1u) << 28));
+}
+static void box_of(const std::vector<BuildTri>& t, uint32_t a, uint32_t b, float* lo, float* hi) {
+    for (int k = 0; k < 3; k++) { lo[k] = 3.0e38f; hi[k] = -3.0e38f; }
+    for (uint32_t i = a; i < b; i++)
+        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], t[i].lo[k]); hi[k] = std::max(hi[k], t[i].hi[k]); }
+}
+static inline float half_area(const float* lo, const float* hi) {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+// conservative padding so that the slab test can never cull a triangle the
+// exact test would accept
+static void pad_box(float* lo, float* hi) {
+    for (int k = 0; k < 3; k++) {
+        float m = std::max(std::fabs(lo[k]), std::fabs(hi[k]));
+        float e = m * 4.0e-6f + (hi[k] - lo[k]) * 4.0e-6f + 1.0e-30f;
+        lo[k] -= e; hi[k] += e;
+    }
+}
+
+static int32_t build_rec(std::vector<BuildTri>& t, uint32_t a, uint32_t b, MeshAccel& acc, int depth) {
+    uint32_t n = b - a;
+    if (n <= 2 || depth > 60) {
+        if (n > 8) { // degenerate fallback: split in the middle
+            uint32_t m = a + n / 2;
+            int32_t idx = (int32_t)acc.nodes.size();
+            acc.nodes.emplace_back();
+            int32_t l = build_rec(t, a, m, acc, depth + 1);
+            int32_t r = build_rec(t, m, b, acc, depth + 1);
+            BNode& nd = acc.nodes[idx];
+            box_of(t, a, m, nd.lo[0], nd.hi[0]); pad_box(nd.lo[0], nd.hi[0]);
+            box_of(t, m, b, nd.lo[1], nd.hi[1]); pad_box(nd.lo[1], nd.hi[1]);
+            nd.child[0] = l; nd.child[1] = r;
+            return idx;
+        }
+        return leaf_code(a, n);
+    }
+    float clo[3] = {3e38f, 3e38f, 3e38f}, chi[3] = {-3e38f, -3e38f, -3e38f};
+    for (uint32_t i = a; i < b; i++)
+        for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], t[i].c[k]); chi[k] = std::max(chi[k], t[i].c[k]); }
+    const int NB = 16;
+    float best_cost = 3e38f; int best_axis = -1, best_split = -1;
+    float plo[3], phi[3];
+    box_of(t, a, b, plo, phi);
+    float parent_area = half_area(plo, phi);
+    for (int ax = 0; ax < 3; ax++) {
+        float ext = chi[ax] - clo[ax];
+        if (!(ext > 0.0f)) continue;
+        float blo[NB][3], bhi[NB][3]; uint32_t bc[NB];
+        for (int i = 0; i < NB; i++) { bc[i] = 0; for (int k = 0; k < 3; k++) { blo[i][k] = 3e38f; bhi[i][k] = -3e38f; } }
+        float scale = (float)NB / ext;
+        for (uint32_t i = a; i < b; i++) {
+            int bi = (int)((t[i].c[ax] - clo[ax]) * scale);
+            if (bi >= NB) bi = NB - 1;
+            if (bi < 0) bi = 0;
+            bc[bi]++;
+            for (int k = 0; k < 3; k++) { blo[bi][k] = std::min(blo[bi][k], t[i].lo[k]); bhi[bi][k] = std::max(bhi[bi][k], t[i].hi[k]); }
+        }
+        float ra[NB]; uint32_t rc[NB];
+        float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f}; uint32_t cnt = 0;
+        for (int i = NB - 1; i >= 1; i--) {
+            cnt += bc[i];
+            for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], blo[i][k]); hi[k] = std::max(hi[k], bhi[i][k]); }
+            ra[i] = cnt ? half_area(lo, hi) : 0.0f; rc[i] = cnt;
+        }
+        for (int k = 0; k < 3; k++) { lo[k] = 3e38f; hi[k] = -3e38f; }
+        cnt = 0;
+        for (int i = 0; i < NB - 1; i++) {
+            cnt += bc[i];
+            for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], blo[i][k]); hi[k] = std::max(hi[k], bhi[i][k]); }
+            if (cnt == 0 || rc[i + 1] == 0) continue;
+            float cost = half_area(lo, hi) * (float)cnt + ra[i + 1] * (float)rc[i + 1];
+            if (cost < best_cost) { best_cost = cost; best_axis = ax; best_split = i; }
+        }
+    }
+    uint32_t mid;
+    if (best_axis < 0 || (n <= 4 && best_cost >= parent_area * (float)n)) {
+        if (n <= 4) return leaf_code(a, n);
+        // all centroids coincide: split by index
+        mid = a + n / 2;
+    } else {
+        float ext = chi[best_axis] - clo[best_axis];
+        float scale = (float)NB / ext;
+        auto it = std::partition(t.begin() + a, t.begin() + b, [&](const BuildTri& tr) {
+            int bi = (int)((tr.c[best_axis] - clo[best_axis]) * scale);
+            if (bi >= NB) bi = NB - 1;
+            if (bi < 0) bi = 0;
+            return bi <= best_split;
+        });
+        mid = (uint32_t)(it - t.begin());
+        if (mid == a || mid == b) mid = a + n / 2;
+    }
+    int32_t idx = (int32_t)acc.nodes.size();
+    acc.nodes.emplace_back();
+    int32_t l = build_rec(t, a, mid, acc, depth + 1);
+    int32_t r = build_rec(t, mid, b, acc, depth + 1);
+    BNode& nd = acc.nodes[idx];
+    box_of(t, a, mid, nd.lo[0], nd.hi[0]); pad_box(nd.lo[0], nd.hi[0]);
+    box_of(t, mid, b, nd.lo[1], nd.hi[1]); pad_box(nd.lo[1], nd.hi[1]);
+    nd.child[0] = l; nd.child[1] = r;
+    return idx;
+}
+
+static void build_accel(const rr_mesh& m, MeshAccel& acc) {
+    std::vector<BuildTri> t(m.n_triangles);
+    for (uint32_t i = 0; i < m.n_triangles; i++) {
+        BuildTri& bt = t[i];
+        bt.id = i;
+        for (int k = 0; k < 3; k++) { bt.lo[k] = 3e38f; bt.hi[k] = -3e38f; }
+        for (int v = 0; v < 3; v++) {
+            const float* p = m.positions + 3 * (size_t)m.indices[3 * (size_t)i + v];
+            for (int k = 0; k < 3; k++) { bt.lo[k] = std::min(bt.lo[k], p[k]); bt.hi[k] = std::max(bt.hi[k], p[k]); }
+        }
+        for (int k = 0; k < 3; k++) bt.c[k] = 0.5f * (bt.lo[k] + bt.hi[k]);
+    }
+    acc.nodes.clear();
+    acc.nodes.reserve(m.n_triangles);
+    acc.root = m.n_triangles ? build_rec(t, 0, m.n_triangles, acc, 0) : 0;
+    acc.order.resize(m.n_triangles);
+    for (uint32_t i = 0; i < m.n_triangles; i++) acc.order[i] = t[i].id;
+}
+
+// conservative slab test: entry distance of [0, tmax] against a padded box
+static inline bool slab(const float* lo, const float* hi, const float* o, const float* inv, float tmax, float* entry) {
+    float t0 = 0.0f, t1 = tmax;
+    for (int k = 0; k < 3; k++) {
+        float a = (lo[k] - o[k]) * inv[k];
+        float b = (hi[k] - o[k]) * inv[k];
+        float n = rs_min(a, b), f = rs_max(a, b); // NaN (0*inf) drops out
+        t0 = rs_max(t0, n);
+        t1 = rs_min(t1, f);
+    }
+    *entry = t0;
+    return t0 <= t1 * 1.0000004f;
+}
+
+// ---------------------------------------------------------------------------
+// scene wrapper
+// ---------------------------------------------------------------------------
+struct OScene {
+    const rr_flat_scene* fs;
+    std::vector<MeshAccel> accel;
+    bool brute_force;
+};
+
+static inline V3 load3(const float* p) { return V3{p[0], p[1], p[2]}; }
+
+struct MeshHit { float toi; V3 normal; uint32_t face_id; };
+
+static inline void tri_vertices(const rr_mesh& m, uint32_t f, V3* a, V3* b, V3* c) {
+    const uint32_t* idx = m.indices + 3 * (size_t)f;
+    *a = load3(m.positions + 3 * (size_t)idx[0]);
+    *b = load3(m.positions + 3 * (size_t)idx[1]);
+    *c = load3(m.positions + 3 * (size_t)idx[2]);
+}
+
+// TriMesh::cast_local_ray_and_get_normal: nearest triangle; FeatureId::Face(i)
+// for front faces, Face(i + n_triangles) for back faces [recalled].
+static bool mesh_cast(const OScene& sc, int mesh_idx, const Ray& ray, MeshHit* out) {
+    const rr_mesh& m = sc.fs->meshes[mesh_idx];
+    bool found = false;
+    float best = 0.0f; uint32_t best_face = 0; TriHit best_hit{};
+    auto test = [&](uint32_t f) {
+        V3 a, b, c;
+        tri_vertices(m, f, &a, &b, &c);
+        CNT(leaf_prims[tl_kind], 1);
+        TriHit h;
+        if (ray_triangle(a, b, c, ray, &h)) {
+            if (!found || h.toi < best || (h.toi == best && f < best_face)) {
+                found = true; best = h.toi; best_face = f; best_hit = h;
+            }
+        }
+    };
+    if (sc.brute_force || m.n_triangles == 0) {
+        for (uint32_t f = 0; f < m.n_triangles; f++) test(f);
+    } else {
+        const MeshAccel& acc = sc.accel[mesh_idx];
+        const float o[3] = {ray.origin.x, ray.origin.y, ray.origin.z};
+        const float inv[3] = {1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z};
+        int32_t stack[128]; int sp = 0;
+        int32_t cur = acc.root;
+        for (;;) {
+            if (cur < 0) {
+                uint32_t code = (uint32_t)~cur;
+                uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
+                for (uint32_t i = 0; i < count; i++) test(acc.order[first + i]);
+                if (sp == 0) break;
+                cur = stack[--sp];
+                continue;
+            }
+            const BNode& nd = acc.nodes[cur];
+            CNT(nodes[tl_kind], 1);
+            float tmax = found ? best : 3.40282347e+38f;
+            float e0, e1;
+            bool h0 = slab(nd.lo[0], nd.hi[0], o, inv, tmax, &e0);
+            bool h1 = slab(nd.lo[1], nd.hi[1], o, inv, tmax, &e1);
+            if (h0 && h1) {
+                int near = (e1 < e0) ? 1 : 0;
+                if (sp < 127) stack[sp++] = nd.child[1 - near];
+                cur = nd.child[near];
+            } else if (h0) cur = nd.child[0];
+            else if (h1) cur = nd.child[1];
+            else { if (sp == 0) break; cur = stack[--sp]; }
+        }
+    }
+    if (!found) return false;
+    out->toi = best;
+    out->normal = best_hit.normal;
+    out->face_id = best_face + (best_hit.back ? m.n_triangles : 0u);
+    return true;
+}
+
+// reference src/shape/mod.rs:755-761
+static inline Ray inverse_ray(const rr_item& it, const Ray& ray) {
+    V4 o = mat_mul(it.trans_inv, ray.origin.x, ray.origin.y, ray.origin.z, 1.0f);
+    V4 d = mat_mul(it.trans_inv, ray.dir.x, ray.dir.y, ray.dir.z, 0.0f);
+    Ray r;
+    r.origin = point_from_h(o);
+    r.dir = V3{d.x, d.y, d.z};
+    return r;
+}
+
+static inline bool item_solid(const rr_material& cache, bool force_not_solid) {
+    // reference src/shape/mesh.rs:56, src/shape/sphere.rs:50 — the cache never holds textures
+    bool has_alpha_tex = cache.texture[RR_TEX_ALPHA] >= 0;
+    return !(cache.alpha < 1.0f || has_alpha_tex) && cache.backface_cullig && !force_not_solid;
+}
+
+// Shape::intersect_b_box (reference src/shape/mesh.rs:51-59, src/shape/sphere.rs:45-52)
+static bool intersect_b_box(const OScene& sc, const rr_item& it, const Ray& ray, bool force_not_solid, float* dist) {
+    CNT(items[tl_kind], 1);
+    Ray ri = inverse_ray(it, ray);
+    bool solid = item_solid(sc.fs->materials[it.material_cache], force_not_solid);
+    return aabb_cast_local_ray(it.bbox_min, it.bbox_max, ri, solid, dist);
+}
+
+// area-ratio barycentric weights shared by Mesh::get_uv / Mesh::get_normal
+// (reference src/shape/mesh.rs:145-152, :238-245)
+static inline void area_weights(V3 a, V3 b, V3 c, V3 p, float* a1, float* a2, float* a3) {
+    V3 f1 = a - p, f2 = b - p, f3 = c - p;
+    float area = norm(cross(a - b, a - c));
+    *a1 = norm(cross(f2, f3)) / area;
+    *a2 = norm(cross(f3, f1)) / area;
+    *a3 = norm(cross(f1, f2)) / area;
+}
+
+// Mesh::get_normal (reference src/shape/mesh.rs:204-259)
+static V3 mesh_get_normal(const rr_item& it, const rr_mesh& m, V3 hit, uint32_t face_id) {
+    V3 p = point_from_h(mat_mul(it.trans_inv, hit.x, hit.y, hit.z, 1.0f));
+    uint32_t f = face_id % m.n_triangles;
+    V3 a, b, c;
+    tri_vertices(m, f, &a, &b, &c);
+    const uint32_t* ni = m.normal_indices + 3 * (size_t)f;
+    V3 na = load3(m.normals + 3 * (size_t)ni[0]);
+    V3 nb = load3(m.normals + 3 * (size_t)ni[1]);
+    V3 nc = load3(m.normals + 3 * (size_t)ni[2]);
+    float a1, a2, a3;
+    area_weights(a, b, c, p, &a1, &a2, &a3);
+    V3 p1 = na * a1, p2 = nb * a2, p3 = nc * a3;
+    return V3{p1.x + p2.x + p3.x, p1.y + p2.y + p3.y, p1.z + p2.z + p3.z};
+}
+
+// Mesh::get_uv (reference src/shape/mesh.rs:105-161)
+static V2 mesh_get_uv(const rr_item& it, const rr_mesh& m, V3 hit, uint32_t face_id) {
+    V3 p = point_from_h(mat_mul(it.trans_inv, hit.x, hit.y, hit.z, 1.0f));
+    uint32_t f = face_id % m.n_triangles;
+    if ((int32_t)m.n_uv_faces - 1 < (int32_t)f || (int32_t)m.n_triangles - 1 < (int32_t)f) return V2{0.0f, 0.0f};
+    V3 a, b, c;
+    tri_vertices(m, f, &a, &b, &c);
+    const uint32_t* ti = m.uv_indices + 3 * (size_t)f;
+    const float* ta = m.uvs + 2 * (size_t)ti[0];
+    const float* tb = m.uvs + 2 * (size_t)ti[1];
+    const float* tc = m.uvs + 2 * (size_t)ti[2];
+    float a1, a2, a3;
+    area_weights(a, b, c, p, &a1, &a2, &a3);
+    float ux = (ta[0] * a1 + tb[0] * a2) + tc[0] * a3;
+    float uy = (ta[1] * a1 + tb[1] * a2) + tc[1] * a3;
+    return V2{ux, -uy};
+}
+
+// Sphere::get_uv (reference src/shape/sphere.rs:69-99)
+static V2 sphere_get_uv(const rr_item& it, V3 hit) {
+    V3 p = point_from_h(mat_mul(it.trans_inv, hit.x, hit.y, hit.z, 1.0f));
+    float theta = atan2_f32(-(p.z - 0.0f), p.x - 0.0f);
+    float u = (theta + RR_PI) / (2.0f * RR_PI);
+    float phi = acos_f32((-(p.y - 0.0f)) / it.radius);
+    float v = phi / RR_PI;
+    return V2{u, -v};
+}
+
+static V2 item_get_uv(const OScene& sc, const rr_item& it, V3 hit, uint32_t face_id) {
+    if (it.kind == RR_ITEM_SPHERE) return sphere_get_uv(it, hit);
+    return mesh_get_uv(it, sc.fs->meshes[it.mesh], hit, face_id);
+}
+
+struct ItemHit { float toi; V3 normal; uint32_t face_id; };
+
+// Shape::intersect (reference src/shape/mesh.rs:61-103, src/shape/sphere.rs:54-67)
+static bool item_intersect(const OScene& sc, const rr_item& it, const Ray& ray, bool force_not_solid, ItemHit* out) {
+    CNT(items[tl_kind], 1);
+    Ray ri = inverse_ray(it, ray);
+    const rr_material& cache = sc.fs->materials[it.material_cache];
+    bool solid = item_solid(cache, force_not_solid);
+    if (it.kind == RR_ITEM_SPHERE) {
+        float toi; V3 n;
+        CNT(leaf_prims[tl_kind], 1);
+        if (!ray_ball(it.radius, ri, solid, &toi, &n)) return false;
+        V4 wn = mat_mul(it.trans, n.x, n.y, n.z, 0.0f);
+        out->toi = toi;
+        out->normal = normalize(V3{wn.x, wn.y, wn.z});
+        out->face_id = 0;
+        return true;
+    }
+    const rr_mesh& m = sc.fs->meshes[it.mesh];
+    MeshHit mh;
+    if (!mesh_cast(sc, it.mesh, ri, &mh)) return false;
+    V3 normal;
+    if (cache.smooth_shading && m.n_normals > 0 && m.n_normal_faces > 0) {
+        V3 hit = ray.origin + (ray.dir * mh.toi);
+        V3 nl = mesh_get_normal(it, m, hit, mh.face_id);
+        V4 wn = mat_mul(it.trans, nl.x, nl.y, nl.z, 0.0f);
+        normal = normalize(V3{wn.x, wn.y, wn.z});
+        if (mh.face_id >= m.n_triangles) normal = -normal; // TriMesh::is_backface
+    } else {
+        V4 wn = mat_mul(it.trans, mh.normal.x, mh.normal.y, mh.normal.z, 0.0f);
+        normal = normalize(V3{wn.x, wn.y, wn.z});
+    }
+    if (it.flip_normals) normal = -normal;
+    out->toi = mh.toi;
+    out->normal = normal;
+    out->face_id = mh.face_id;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// Raytracing::trace (reference src/raytracing.rs:429-490)
+// ---------------------------------------------------------------------------
+struct TraceHit { float toi; V3 normal; int item; uint32_t face_id; };
+
+static bool trace(const OScene& sc, const Ray& ray, bool stop_on_first_hit, bool for_shadow, uint16_t depth, TraceHit* out) {
+    tl_kind = for_shadow ? 1 : 0;
+    const rr_flat_scene* fs = sc.fs;
+    struct Cand { int item; float dist; };
+    std::vector<Cand> hits;
+    hits.reserve(fs->n_items);
+    for (uint32_t i = 0; i < fs->n_items; i++) {
+        const rr_item& it = fs->items[i];
+        float dist;
+        if (intersect_b_box(sc, it, ray, for_shadow, &dist)) {
+            const rr_material& mat = fs->materials[it.material_cache];
+            if (it.visible && mat.alpha > 0.0f && (!for_shadow || mat.cast_shadow) && (!mat.reflection_only || depth > 1)) {
+                if (dist == dist) hits.push_back(Cand{(int)i, dist}); // D3: NaN distance = miss
+            }
+        }
+    }
+    if (hits.empty()) return false;
+    std::stable_sort(hits.begin(), hits.end(), [](const Cand& a, const Cand& b) { return a.dist < b.dist; });
+    bool have = false;
+    TraceHit best{};
+    for (const Cand& c : hits) {
+        ItemHit ih;
+        if (item_intersect(sc, fs->items[c.item], ray, for_shadow, &ih)) {
+            if (!have || ih.toi < best.toi) {
+                have = true;
+                best = TraceHit{ih.toi, ih.normal, c.item, ih.face_id};
+            }
+        }
+        if (have && stop_on_first_hit) break;
+    }
+    if (have) *out = best;
+    return have;
+}
+
+// ---------------------------------------------------------------------------
+// textures (reference src/raytracing.rs:629-675, src/shape/mod.rs:510-629)
+// ---------------------------------------------------------------------------
+static inline V4 texel(const rr_texture& t, uint32_t x, uint32_t y) {
+    CNT(texels, 1);
+    const uint8_t* p = t.rgba8 + 4 * ((size_t)y * t.width + x);
+    return V4{(float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, (float)p[3] / 255.0f};
+}
+static inline uint32_t wrap(float val, uint32_t bound) {
+    int32_t signed_bound = (int32_t)bound;
+    float float_coord = val * (float)bound;
+    int32_t wrapped = as_i32(float_coord) % signed_bound;
+    return (wrapped < 0) ? (uint32_t)(wrapped + signed_bound) : (uint32_t)wrapped;
+}
+static V4 tex_interpolate(const rr_texture& t, float xf, float yf) {
+    uint32_t width = t.width, height = t.height;
+    float x = xf * (float)width;
+    float y = yf * (float)height;
+    if (x < 0.0f) x = x + (float)width;
+    if (y < 0.0f) y = y + (float)height;
+    uint32_t x0 = as_u32(std::floor(x)), x1 = as_u32(std::ceil(x));
+    uint32_t y0 = as_u32(std::floor(y)), y1 = as_u32(std::ceil(y));
+    if (x0 >= width) x0 = width - 1;
+    if (y0 >= height) y0 = height - 1;
+    if (x1 >= width) x1 = width - 1;
+    if (y1 >= height) y1 = height - 1;
+    float fx = x - (float)x0;
+    float fy = y - (float)y0;
+    V4 p0 = texel(t, x0, y0), p1 = texel(t, x1, y0), p2 = texel(t, x0, y1), p3 = texel(t, x1, y1);
+    V4 r1{interpolate(p0.x, p1.x, fx), interpolate(p0.y, p1.y, fx), interpolate(p0.z, p1.z, fx), interpolate(p0.w, p1.w, fx)};
+    V4 r2{interpolate(p2.x, p3.x, fx), interpolate(p2.y, p3.y, fx), interpolate(p2.z, p3.z, fx), interpolate(p2.w, p3.w, fx)};
+    return V4{interpolate(r1.x, r2.x, fy), interpolate(r1.y, r2.y, fy), interpolate(r1.z, r2.z, fy), interpolate(r1.w, r2.w, fy)};
+}
+// get_tex_color: returns false for "None"
+static bool get_tex_color(const OScene& sc, const rr_material& mat, bool has_uv, V2 uv, int tex_type, V4* out) {
+    int ti = mat.texture[tex_type];
+    if (ti < 0 || !has_uv) return false;
+    const rr_texture& t = sc.fs->textures[ti];
+    if (t.width == 0) return false; // has_texture: width > 0
+    if (mat.texture_filtering_nearest) {
+        uint32_t tx = wrap(uv.x, t.width);
+        uint32_t ty = wrap(uv.y, t.height);
+        *out = texel(t, tx, ty);
+    } else {
+        *out = tex_interpolate(t, uv.x, uv.y);
+    }
+    return true;
+}
+static bool has_any_texture(const OScene& sc, const rr_material& mat) {
+    for (int k = 0; k < RR_TEX_COUNT; k++)
+        if (mat.texture[k] >= 0 && sc.fs->textures[mat.texture[k]].width > 0) return true;
+    return false;
+}
+// get_item_color (reference src/raytracing.rs:677-712)
+static V4 get_item_color(const OScene& sc, const rr_material& mat, bool has_uv, V2 uv, const float* rgb, int tex_type) {
+    V4 c{rgb[0], rgb[1], rgb[2], 1.0f};
+    V4 t;
+    if (get_tex_color(sc, mat, has_uv, uv, tex_type, &t)) { c.x *= t.x; c.y *= t.y; c.z *= t.z; c.w *= t.w; }
+    return c;
+}
+
+// ---------------------------------------------------------------------------
+// counter-based RNG (divergence D1) and jitter (reference src/raytracing.rs:565-626)
+// ---------------------------------------------------------------------------
+static inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct RngCtx { uint64_t seed; uint32_t pixel; uint32_t sample; };
+
+// rand 0.8 UniformFloat<f32>::sample_single [recalled]: 23 random mantissa bits ->
+// [1,2) - 1, scaled; the (rare) res >= high retry is replaced by clamping to the
+// float just below `high` because a counter-based stream has no "next draw".
+static inline float uniform_f32(uint32_t bits, float low, float high) {
+    float scale = high - low;
+    float value1_2 = u2f((bits >> 9) | 0x3f800000u);
+    float value0_1 = value1_2 - 1.0f;
+    float res = value0_1 * scale + low;
+    if (!(res < high)) res = u2f(f2u(high) - 1u); // high is positive on both call sites
+    return res;
+}
+
+static V3 jitter(V3 dir, float spread, const RngCtx& rc, uint32_t node, uint32_t stream) {
+    if (spread <= 0.0f) return dir;
+    V3 b3 = normalize(dir);
+    V3 diff = (rs_abs(b3.x) < 0.5f) ? v3(1.0f, 0.0f, 0.0f) : v3(0.0f, 1.0f, 0.0f);
+    V3 b1 = normalize(cross(b3, diff));
+    V3 b2 = cross(b1, b3);
+    float z_lo = cos_f32(spread * RR_PI);
+    if (!(z_lo < 1.0f)) return dir; // Range::is_empty
+    uint32_t ctr[4] = {rc.pixel, rc.sample, node, stream};
+    uint32_t key[2] = {(uint32_t)rc.seed, (uint32_t)(rc.seed >> 32)};
+    uint32_t rnd[4];
+    philox4x32_10(ctr, key, rnd);
+    float z = uniform_f32(rnd[0], z_lo, 1.0f);
+    float r = std::sqrt(1.0f - z * z);
+    float theta = uniform_f32(rnd[1], -RR_PI, RR_PI);
+    float s, c;
+    sincos_f32(theta, &s, &c);
+    float x = r * c;
+    float y = r * s;
+    V3 nd = (x * b1 + y * b2) + z * b3;
+    return normalize(nd);
+}
+
+// ---------------------------------------------------------------------------
+// secondary rays (reference src/raytracing.rs:492-563, :714-718)
+// ---------------------------------------------------------------------------
+static const float SHADOW_BIAS = 0.001f;
+
+static Ray create_reflection(V3 normal, V3 incident, V3 p) {
+    Ray r;
+    r.origin = p + (normal * SHADOW_BIAS);
+    r.dir = incident - ((2.0f * dot(incident, normal)) * normal);
+    return r;
+}
+static bool create_transmission(V3 normal, V3 incident, V3 p, float index, Ray* out) {
+    V3 ref_n = normal;
+    float eta_t = index, eta_i = 1.0f;
+    float i_dot_n = dot(incident, normal);
+    if (i_dot_n < 0.0f) {
+        i_dot_n = -i_dot_n;
+    } else {
+        ref_n = -normal;
+        eta_t = 1.0f;
+        eta_i = index;
+    }
+    float eta = eta_i / eta_t;
+    float k = 1.0f - (eta * eta) * (1.0f - i_dot_n * i_dot_n);
+    if (k < 0.0f) return false;
+    out->origin = p + (ref_n * -SHADOW_BIAS);
+    out->dir = ((incident + i_dot_n * ref_n) * eta) - (ref_n * std::sqrt(k));
+    return true;
+}
+static float fresnel(V3 incident, V3 normal, float index) {
+    float i_dot_n = dot(incident, normal);
+    float eta_i = 1.0f, eta_t = index;
+    if (i_dot_n > 0.0f) { eta_i = eta_t; eta_t = 1.0f; }
+    float sin_t = eta_i / eta_t * std::sqrt(rs_max(1.0f - i_dot_n * i_dot_n, 0.0f));
+    if (sin_t > 1.0f) return 1.0f;
+    float cos_t = std::sqrt(rs_max(1.0f - sin_t * sin_t, 0.0f));
+    float cos_i = rs_abs(cos_t);
+    float r_s = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_i * cos_t));
+    float r_p = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
+    return (r_s * r_s + r_p * r_p) / 2.0f;
+}
+static inline V3 reflect(V3 i, V3 n) { return i - ((2.0f * dot(n, i)) * n); }
+
+// ---------------------------------------------------------------------------
+// get_color_depth_normal_id (reference src/raytracing.rs:720-998)
+// ---------------------------------------------------------------------------
+struct Shade { V3 color; float depth; V3 normal; uint32_t id; };
+
+struct RenderCtx {
+    const OScene* sc;
+    const rr_config* cfg;
+    RngCtx rng;
+    bool count_primary;
+};
+
+static Shade get_color_depth_normal_id(const RenderCtx& rc, Ray ray, uint16_t depth, uint32_t node) {
+    const OScene& sc = *rc.sc;
+    const rr_flat_scene* fs = sc.fs;
+    const rr_config& cfg = *rc.cfg;
+    Ray r = ray;
+    r.dir = normalize(r.dir);
+    if (depth == 1) CNT(rays_primary, 1); else CNT(rays_secondary, 1);
+
+    Shade out{v3(0, 0, 0), 0.0f, v3(0, 0, 0), 0u};
+    TraceHit hit;
+    if (!trace(sc, r, false, false, depth, &hit)) return out;
+    CNT(shaded_hits, 1);
+
+    const rr_item& item = fs->items[hit.item];
+    const rr_material& material = fs->materials[item.material];
+    float hit_dist = hit.toi;
+    V3 normal = hit.normal;
+    out.depth = hit_dist;
+    out.normal = normal;
+    out.id = item.id;
+
+    V3 surface_normal = normal;
+    V3 hit_point = r.origin + (r.dir * hit_dist);
+
+    bool has_uv = false;
+    V2 uv{0, 0};
+    if (has_any_texture(sc, material)) { uv = item_get_uv(sc, item, hit_point, hit.face_id); has_uv = true; }
+
+    // normal mapping (:757-784)
+    V4 ntc;
+    if (get_tex_color(sc, material, has_uv, uv, RR_TEX_NORMAL, &ntc)) {
+        V3 tangent = cross(normal, v3(0.0f, 1.0f, 0.0f));
+        if (norm(tangent) <= 0.0001f) tangent = cross(normal, v3(0.0f, 0.0f, 1.0f));
+        tangent = normalize(tangent);
+        V3 bitangent = normalize(cross(normal, tangent));
+        V3 nm = v3(ntc.x, ntc.y, ntc.z);
+        nm.x = (nm.x * 2.0f) - 1.0f;
+        nm.y = (nm.y * 2.0f) - 1.0f;
+        nm.z = (nm.z * 2.0f) - 1.0f;
+        nm.x *= material.normal_map_strength;
+        nm.y *= material.normal_map_strength;
+        nm = normalize(nm);
+        // tbn * nm with tbn columns (tangent, bitangent, normal): column axpy order
+        V3 t;
+        t.x = (tangent.x * nm.x + bitangent.x * nm.y) + normal.x * nm.z;
+        t.y = (tangent.y * nm.x + bitangent.y * nm.y) + normal.y * nm.z;
+        t.z = (tangent.z * nm.x + bitangent.z * nm.y) + normal.z * nm.z;
+        surface_normal = normalize(t);
+    }
+
+    // roughness (:787-798)
+    V4 rtc;
+    bool has_rtc = get_tex_color(sc, material, has_uv, uv, RR_TEX_ROUGHNESS, &rtc);
+    if (cfg.monte_carlo && material.monte_carlo && (material.roughness > 0.0f || has_rtc)) {
+        float roughness = material.roughness;
+        if (has_rtc) roughness = (1.0f / RR_PI / 2.0f) * rtc.x;
+        surface_normal = jitter(surface_normal, roughness, rc.rng, node, 0u);
+    }
+
+    V4 ambient_color = get_item_color(sc, material, has_uv, uv, material.ambient_color, RR_TEX_AMBIENT_EMISSIVE);
+    V4 base_color = get_item_color(sc, material, has_uv, uv, material.base_color, RR_TEX_BASE);
+    V4 specular_color = get_item_color(sc, material, has_uv, uv, material.specular_color, RR_TEX_SPECULAR);
+
+    float alpha = material.alpha * base_color.w;
+    V4 atc;
+    if (get_tex_color(sc, material, has_uv, uv, RR_TEX_ALPHA, &atc)) alpha *= atc.x;
+
+    V3 color = v3(0, 0, 0);
+
+    for (uint32_t li = 0; li < fs->n_lights; li++) {
+        const rr_light& light = fs->lights[li];
+        if (!light.enabled) continue;
+        V3 lpos = load3(light.pos), ldir = load3(light.dir);
+        V3 direction_to_light;
+        if (light.light_type == RR_LIGHT_DIRECTIONAL) direction_to_light = normalize(-ldir);
+        else direction_to_light = normalize(lpos - hit_point);
+
+        float dot_light = rs_max(dot(surface_normal, direction_to_light), 0.0f);
+        V4 base{base_color.x * dot_light, base_color.y * dot_light, base_color.z * dot_light, base_color.w * dot_light};
+
+        V3 reflect_dir = reflect(-direction_to_light, surface_normal);
+        V3 view_dir = normalize(-r.dir);
+        float spec_dot = rs_max(dot(reflect_dir, view_dir), 0.0f);
+        float light_power = std::pow(spec_dot, material.shininess);
+        V4 specular{specular_color.x * light_power, specular_color.y * light_power, specular_color.z * light_power, specular_color.w * light_power};
+
+        float intensity;
+        if (light.light_type == RR_LIGHT_DIRECTIONAL) {
+            intensity = light.intensity;
+        } else {
+            float r2 = norm(lpos - hit_point);
+            intensity = light.intensity / (4.0f * RR_PI * r2);
+            if (light.light_type == RR_LIGHT_SPOT) {
+                V3 light_dir = normalize(ldir);
+                float d = dot(-direction_to_light, light_dir);
+                float angle = acos_f32(d);
+                if (angle > light.max_angle) intensity = 0.0f;
+            }
+        }
+
+        if (material.receive_shadow) {
+            V3 shadow_ray_start = hit_point + (surface_normal * SHADOW_BIAS);
+            V3 shadow_ray_dir = direction_to_light;
+            if (cfg.monte_carlo && material.monte_carlo)
+                shadow_ray_dir = jitter(shadow_ray_dir, material.shadow_softness, rc.rng, node, 1u + li);
+            Ray shadow_ray{shadow_ray_start, shadow_ray_dir};
+            CNT(rays_shadow, 1);
+            TraceHit sh;
+            bool shit = trace(sc, shadow_ray, true, true, depth, &sh);
+            tl_kind = 0;
+            bool in_light = !shit;
+            if (!in_light && (light.light_type == RR_LIGHT_POINT || light.light_type == RR_LIGHT_SPOT)) {
+                float len = norm(lpos - hit_point);
+                in_light = sh.toi > len;
+            }
+            if (!in_light) {
+                const rr_item& shadow_obj = fs->items[sh.item];
+                float shadow_source_alpha = material.alpha;
+                const rr_material& som = fs->materials[shadow_obj.material];
+                V3 shadow_hit_point = shadow_ray.origin + (shadow_ray.dir * sh.toi);
+                // the reference evaluates the RECEIVER's get_uv with the occluder's face id (:905)
+                if (som.texture[RR_TEX_ALPHA] >= 0 && fs->textures[som.texture[RR_TEX_ALPHA]].width > 0) {
+                    V2 shadow_uv = item_get_uv(sc, item, shadow_hit_point, sh.face_id);
+                    V4 satc;
+                    if (get_tex_color(sc, som, true, shadow_uv, RR_TEX_ALPHA, &satc)) shadow_source_alpha *= satc.x;
+                }
+                intensity = intensity * (1.0f - shadow_source_alpha);
+            }
+        }
+
+        color.x = color.x + ((light.color[0] * (specular.x + base.x)) * intensity);
+        color.y = color.y + ((light.color[1] * (specular.y + base.y)) * intensity);
+        color.z = color.z + ((light.color[2] * (specular.z + base.z)) * intensity);
+    }
+
+    float refraction_index = material.refraction_index;
+    float kr = fresnel(r.dir, surface_normal, refraction_index);
+
+    float reflectivity = material.reflectivity;
+    V4 rftc;
+    if (get_tex_color(sc, material, has_uv, uv, RR_TEX_REFLECTIVITY, &rftc)) reflectivity = rftc.x;
+
+    color = color * (1.0f - reflectivity);
+
+    if (reflectivity > 0.0f && depth <= cfg.max_recursion) {
+        Ray rr = create_reflection(surface_normal, r.dir, hit_point);
+        V3 rc_col = get_color_depth_normal_id(rc, rr, (uint16_t)(depth + 1), node * 2u).color;
+        color = color + (rc_col * reflectivity);
+    }
+
+    if (alpha < 1.0f && depth <= cfg.max_recursion) {
+        Ray tr;
+        if (create_transmission(surface_normal, r.dir, hit_point, refraction_index, &tr)) {
+            Shade ts = get_color_depth_normal_id(rc, tr, (uint16_t)(depth + 1), node * 2u + 1u);
+            V3 refr = ts.color;
+            if (kr < 1.0f) color = (color * alpha) + ((refr * (1.0f - kr)) * (1.0f - alpha));
+            else color = (color * alpha) + (refr * (1.0f - alpha));
+            if (approx_equal(alpha, 0.0f)) out.id = ts.id;
+        }
+    } else if (alpha < 1.0f) {
+        color = color * alpha;
+    }
+
+    {
+        float fog_amount = rs_min(cfg.fog_density * hit_dist, 1.0f);
+        V3 fc = load3(cfg.fog_color);
+        color = ((1.0f - fog_amount) * color) + (fc * fog_amount);
+    }
+
+    V4 ao;
+    if (get_tex_color(sc, material, has_uv, uv, RR_TEX_AMBIENT_OCCLUSION, &ao)) {
+        color.x *= ao.x; color.y *= ao.x; color.z *= ao.x;
+    }
+
+    color = color + v3(ambient_color.x, ambient_color.y, ambient_color.z);
+    out.color = color;
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// Raytracing::render (reference src/raytracing.rs:275-427)
+// ---------------------------------------------------------------------------
+static const float CAM_CLIPPING_PLANE_DIST = 1.0f;
+static const float APERTURE_BASE_RESOLUTION = 800.0f;
+
+static uint32_t cell_size_for(uint16_t samples) {
+    if (samples <= 1) return 1;
+    uint16_t v = (uint16_t)(samples + 2); // u16 arithmetic (:297)
+    uint32_t p = 1;
+    while (p < v) p <<= 1; // next_power_of_two
+    return p / 2;
+}
+
+static Ray make_primary(const rr_camera& cam, const rr_config& cfg, int x, int y, uint16_t x_i, uint16_t y_i, uint32_t cell_size) {
+    float x_f = (float)x, y_f = (float)y;
+    float w = (float)cam.width, h = (float)cam.height;
+    float x_step = 2.0f / w, y_step = 2.0f / h;
+    float x_trans = x_step * (float)x_i * (1.0f / (float)cell_size);
+    float y_trans = y_step * (float)y_i * (1.0f / (float)cell_size);
+    bool dof = cfg.aperture_size > 1.0f && cfg.focal_length > 1.0f;
+    if (dof && cfg.samples > 1) {
+        x_trans -= x_step / 2.0f;
+        y_trans -= y_step / 2.0f;
+    }
+    Ray ray;
+    if (dof) {
+        float aperture_scale = (float)cam.width / APERTURE_BASE_RESOLUTION;
+        x_trans *= cfg.aperture_size * aperture_scale;
+        y_trans *= cfg.aperture_size * aperture_scale;
+        float center_x = ((x_f + 0.5f) / w) * 2.0f - 1.0f;
+        float center_y = 1.0f - ((y_f + 0.5f) / h) * 2.0f;
+        V4 cpp = mat_mul(cam.projection_inverse, center_x, center_y, -CAM_CLIPPING_PLANE_DIST, 1.0f);
+        cpp.w = 1.0f;
+        V4 ray_dir{cpp.x - 0.0f, cpp.y - 0.0f, cpp.z - 0.0f, 0.0f};
+        V4 origin = mat_mul(cam.view_inverse, 0.0f, 0.0f, 0.0f, 1.0f);
+        V4 dirv = mat_mul(cam.view_inverse, ray_dir.x, ray_dir.y, ray_dir.z, ray_dir.w);
+        // Vector4::normalize over all four components (w = 0 for an affine view matrix);
+        // nalgebra's 4-lane dot sums as (x*x + z*z) + (y*y + w*w) [recalled]
+        float dn = std::sqrt((dirv.x * dirv.x + dirv.z * dirv.z) + (dirv.y * dirv.y + dirv.w * dirv.w));
+        V4 dir{dirv.x / dn, dirv.y / dn, dirv.z / dn, dirv.w / dn};
+        float dist = norm(V3{ray_dir.x, ray_dir.y, ray_dir.z});
+        float dist_perpendicular = CAM_CLIPPING_PLANE_DIST;
+        float f = dist_perpendicular / (dist / (dist + cfg.focal_length));
+        V4 p{origin.x + f * dir.x, origin.y + f * dir.y, origin.z + f * dir.z, origin.w + f * dir.w};
+        float ray_sensor_x = (((x_f + 0.5f) / w) * 2.0f - 1.0f) + x_trans;
+        float ray_sensor_y = (1.0f - ((y_f + 0.5f) / h) * 2.0f) + y_trans;
+        V4 pp = mat_mul(cam.projection_inverse, ray_sensor_x, ray_sensor_y, -CAM_CLIPPING_PLANE_DIST, 1.0f);
+        pp.w = 1.0f;
+        V4 ro = mat_mul(cam.view_inverse, pp.x, pp.y, pp.z, pp.w);
+        ray.origin = V3{ro.x, ro.y, ro.z};
+        ray.dir = V3{p.x - ro.x, p.y - ro.y, p.z - ro.z};
+    } else {
+        float sensor_x = (((x_f + 0.5f) / w) * 2.0f - 1.0f) + x_trans;
+        float sensor_y = (1.0f - ((y_f + 0.5f) / h) * 2.0f) + y_trans;
+        V4 pp = mat_mul(cam.projection_inverse, sensor_x, sensor_y, -CAM_CLIPPING_PLANE_DIST, 1.0f);
+        pp.w = 1.0f;
+        V4 rd{pp.x - 0.0f, pp.y - 0.0f, pp.z - 0.0f, 0.0f};
+        V4 o = mat_mul(cam.view_inverse, pp.x, pp.y, pp.z, pp.w);
+        V4 d = mat_mul(cam.view_inverse, rd.x, rd.y, rd.z, rd.w);
+        ray.origin = V3{o.x, o.y, o.z};
+        ray.dir = V3{d.x, d.y, d.z};
+    }
+    return ray;
+}
+
+struct Pixel { uint8_t r, g, b; V3 normal; float depth; uint32_t id; };
+
+static Pixel render_pixel(const OScene& sc, const rr_camera& cam, const rr_config& cfg,
+                          const uint16_t* sample_xy, uint32_t cell_size, int x, int y) {
+    V3 color = v3(0, 0, 0);
+    float depth = 0.0f;
+    V3 normal = v3(0, 0, 0);
+    uint32_t object_id = 0;
+    uint32_t n = cfg.samples;
+    RenderCtx rc;
+    rc.sc = &sc; rc.cfg = &cfg;
+    rc.rng.seed = cfg.seed;
+    rc.rng.pixel = (uint32_t)y * cam.width + (uint32_t)x;
+    for (uint32_t s = 0; s < n; s++) {
+        Ray ray = make_primary(cam, cfg, x, y, sample_xy[2 * s], sample_xy[2 * s + 1], cell_size);
+        rc.rng.sample = s;
+        Shade res = get_color_depth_normal_id(rc, ray, 1, 1u);
+        color = color + res.color;
+        depth += res.depth;
+        normal = normal + res.normal;
+        object_id = res.id;
+    }
+    float nf = (float)n;
+    color = color / nf;
+    depth /= nf;
+    normal = normal / nf;
+    color.x = rs_min(color.x, 1.0f);
+    color.y = rs_min(color.y, 1.0f);
+    color.z = rs_min(color.z, 1.0f);
+    Pixel p;
+    p.r = as_u8(color.x * 255.0f);
+    p.g = as_u8(color.y * 255.0f);
+    p.b = as_u8(color.z * 255.0f);
+    if (cfg.gamma_correction) {
+        const float inv_gamma = 1.0f / 2.2f;
+        p.r = as_u8(std::pow(color.x, inv_gamma) * 255.0f);
+        p.g = as_u8(std::pow(color.y, inv_gamma) * 255.0f);
+        p.b = as_u8(std::pow(color.z, inv_gamma) * 255.0f);
+    }
+    p.depth = depth;
+    p.id = object_id;
+    p.normal = normalize(normal);
+    return p;
+}
+
+// ---------------------------------------------------------------------------
+// sub-sample table (reference src/raytracing.rs:290-313) with rand 0.8's
+// StdRng::seed_from_u64(0) + SliceRandom::shuffle restated [recalled]
+// ---------------------------------------------------------------------------
+static inline uint32_t rotl32(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
+static void chacha_block(const uint32_t key[8], uint64_t counter, int rounds, uint32_t out[16]) {
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
+                      key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                      (uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+    uint32_t x[16];
+    std::memcpy(x, s, sizeof x);
+#define QR(a, b, c, d) \
+    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 16); x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 12); \
+    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 8);  x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 7);
+    for (int i = 0; i < rounds; i += 2) {
+        QR(0, 4, 8, 12) QR(1, 5, 9, 13) QR(2, 6, 10, 14) QR(3, 7, 11, 15)
+        QR(0, 5, 10, 15) QR(1, 6, 11, 12) QR(2, 7, 8, 13) QR(3, 4, 9, 14)
+    }
+#undef QR
+    for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+}
+struct StdRng {
+    uint32_t key[8]; uint64_t counter; uint32_t buf[16]; int idx;
+    explicit StdRng(uint64_t state) {
+        // rand_core SeedableRng::seed_from_u64: PCG32 stream fills the 32-byte seed
+        const uint64_t MUL = 6364136223846793005ull, INC = 11634580027462260723ull;
+        for (int i = 0; i < 8; i++) {
+            state = state * MUL + INC;
+            uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+            uint32_t rot = (uint32_t)(state >> 59);
+            key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+        }
+        counter = 0; idx = 16;
+    }
+    uint32_t next_u32() {
+        if (idx >= 16) { chacha_block(key, counter++, 12, buf); idx = 0; }
+        return buf[idx++];
+    }
+    // UniformInt<u32>::sample_single(0, ubound) [recalled, rand 0.8.5]
+    uint32_t gen_index(uint32_t ubound) {
+        uint32_t range = ubound;
+        int lz = __builtin_clz(range);
+        uint32_t zone = (range << lz) - 1u;
+        for (;;) {
+            uint32_t v = next_u32();
+            uint64_t m = (uint64_t)v * range;
+            uint32_t hi = (uint32_t)(m >> 32), lo = (uint32_t)m;
+            if (lo <= zone) return hi;
+        }
+    }
+};
+
+extern "C" {
+
+int rro_sample_table(uint16_t samples, uint16_t* xy_out, uint32_t* cell_size_out) {
+    uint32_t cs = cell_size_for(samples);
+    std::vector<std::pair<uint16_t, uint16_t>> cells;
+    cells.reserve((size_t)cs * cs);
+    for (uint32_t xi = 0; xi < cs; xi++)
+        for (uint32_t yi = 0; yi < cs; yi++) cells.emplace_back((uint16_t)xi, (uint16_t)yi);
+    StdRng rng(0);
+    for (size_t i = cells.size() - 1; i >= 1; i--) {
+        uint32_t j = rng.gen_index((uint32_t)(i + 1));
+        std::swap(cells[i], cells[j]);
+    }
+    for (uint32_t s = 0; s < samples && s < cells.size(); s++) { xy_out[2 * s] = cells[s].first; xy_out[2 * s + 1] = cells[s].second; }
+    if (cell_size_out) *cell_size_out = cs;
+    return 0;
+}
+
+// Render the window [x0,x1) x [y0,y1) of the frame with n_threads worker threads
+// pulling shuffled 2x2 cells (mirrors reference src/renderer.rs:17, :125-172).
+// Outputs are full-frame buffers (only the window is written).
+int rro_render(const rr_flat_scene* fs, const rr_camera* cam, const rr_config* cfg,
+               const uint16_t* sample_xy, const rr_frame* out,
+               int x0, int y0, int x1, int y1, int n_threads, int brute_force, rro_counters* counters) {
+    if (!fs || !cam || !cfg || !out || !out->rgba8) return -1;
+    OScene sc;
+    sc.fs = fs;
+    sc.brute_force = brute_force != 0;
+    sc.accel.resize(fs->n_meshes);
+    if (!sc.brute_force)
+        for (uint32_t i = 0; i < fs->n_meshes; i++) build_accel(fs->meshes[i], sc.accel[i]);
+    std::vector<uint16_t> table;
+    uint32_t cell_size = cell_size_for(cfg->samples);
+    if (!sample_xy) {
+        table.resize((size_t)cfg->samples * 2);
+        rro_sample_table(cfg->samples, table.data(), &cell_size);
+        sample_xy = table.data();
+    }
+    struct Cell { int x0, y0, x1, y1; };
+    std::vector<Cell> cells;
+    for (int x = x0; x < x1; x += 2)
+        for (int y = y0; y < y1; y += 2) cells.push_back(Cell{x, y, std::min(x + 2, x1), std::min(y + 2, y1)});
+    // deterministic shuffle (the order has no effect on the result)
+    uint64_t lcg = 0x9E3779B97F4A7C15ull;
+    for (size_t i = cells.size(); i > 1; i--) {
+        lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+        size_t j = (size_t)((lcg >> 33) % i);
+        std::swap(cells[i - 1], cells[j]);
+    }
+    if (n_threads < 1) n_threads = 1;
+    std::atomic<size_t> next{0};
+    std::vector<rro_counters> tcnt(n_threads);
+    std::memset(tcnt.data(), 0, sizeof(rro_counters) * n_threads);
+    auto worker = [&](int tid) {
+        tl_cnt = counters ? &tcnt[tid] : nullptr;
+        for (;;) {
+            size_t i = next.fetch_add(1);
+            if (i >= cells.size()) break;
+            const Cell& c = cells[i];
+            for (int y = c.y0; y < c.y1; y++)
+                for (int x = c.x0; x < c.x1; x++) {
+                    Pixel p = render_pixel(sc, *cam, *cfg, sample_xy, cell_size, x, y);
+                    size_t pi = (size_t)y * cam->width + x;
+                    out->rgba8[4 * pi + 0] = p.r; out->rgba8[4 * pi + 1] = p.g;
+                    out->rgba8[4 * pi + 2] = p.b; out->rgba8[4 * pi + 3] = 255;
+                    if (out->normal) { out->normal[3 * pi] = p.normal.x; out->normal[3 * pi + 1] = p.normal.y; out->normal[3 * pi + 2] = p.normal.z; }
+                    if (out->depth) out->depth[pi] = p.depth;
+                    if (out->object_id) out->object_id[pi] = p.id;
+                }
+        }
+        tl_cnt = nullptr;
+    };
+    if (n_threads == 1) worker(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; t++) th.emplace_back(worker, t);
+        for (auto& t : th) t.join();
+    }
+    if (counters) {
+        std::memset(counters, 0, sizeof *counters);
+        for (auto& c : tcnt) {
+            counters->rays_primary += c.rays_primary; counters->rays_secondary += c.rays_secondary;
+            counters->rays_shadow += c.rays_shadow; counters->shaded_hits += c.shaded_hits; counters->texels += c.texels;
+            for (int k = 0; k < 2; k++) { counters->nodes[k] += c.nodes[k]; counters->leaf_prims[k] += c.leaf_prims[k]; counters->items[k] += c.items[k]; }
+        }
+    }
+    return 0;
+}
+
+// Raytracing::pick (reference src/raytracing.rs:237-273)
+int rro_pick(const rr_flat_scene* fs, const rr_camera* cam, int x, int y, rr_pick_result* res) {
+    OScene sc; sc.fs = fs; sc.brute_force = false;
+    sc.accel.resize(fs->n_meshes);
+    for (uint32_t i = 0; i < fs->n_meshes; i++) build_accel(fs->meshes[i], sc.accel[i]);
+    rr_config cfg; std::memset(&cfg, 0, sizeof cfg); cfg.samples = 1; cfg.focal_length = 1.0f; cfg.aperture_size = 1.0f;
+    Ray ray = make_primary(*cam, cfg, x, y, 0, 0, 1);
+    ray.dir = normalize(ray.dir);
+    TraceHit h;
+    std::memset(res, 0, sizeof *res);
+    if (trace(sc, ray, false, false, 1, &h)) {
+        res->hit = 1; res->object_id = fs->items[h.item].id; res->item_index = (uint32_t)h.item; res->distance = h.toi;
+    }
+    return 0;
+}
+
+// ---- unit-level entry points for known-answer tests -------------------------
+int rro_ray_aabb(const float* mins, const float* maxs, const float* origin, const float* dir, int solid, float* toi) {
+    Ray r{load3(origin), load3(dir)};
+    return aabb_cast_local_ray(mins, maxs, r, solid != 0, toi) ? 1 : 0;
+}
+int rro_ray_triangle(const float* a, const float* b, const float* c, const float* origin, const float* dir,
+                     float* toi, float* normal, int* back) {
+    Ray r{load3(origin), load3(dir)};
+    TriHit h;
+    if (!ray_triangle(load3(a), load3(b), load3(c), r, &h)) return 0;
+    *toi = h.toi; normal[0] = h.normal.x; normal[1] = h.normal.y; normal[2] = h.normal.z; *back = h.back;
+    return 1;
+}
+int rro_ray_ball(float radius, const float* origin, const float* dir, int solid, float* toi, float* normal) {
+    Ray r{load3(origin), load3(dir)};
+    V3 n;
+    if (!ray_ball(radius, r, solid != 0, toi, &n)) return 0;
+    normal[0] = n.x; normal[1] = n.y; normal[2] = n.z;
+    return 1;
+}
+uint32_t rro_wrap(float v, uint32_t bound) { return wrap(v, bound); }
+void rro_tex_interpolate(const rr_texture* t, float u, float v, float* rgba) {
+    V4 r = tex_interpolate(*t, u, v);
+    rgba[0] = r.x; rgba[1] = r.y; rgba[2] = r.z; rgba[3] = r.w;
+}
+float rro_fresnel(const float* incident, const float* normal, float index) { return fresnel(load3(incident), load3(normal), index); }
+int rro_transmission(const float* normal, const float* incident, const float* p, float index, float* origin, float* dir) {
+    Ray r;
+    if (!create_transmission(load3(normal), load3(incident), load3(p), index, &r)) return 0;
+    origin[0] = r.origin.x; origin[1] = r.origin.y; origin[2] = r.origin.z; dir[0] = r.dir.x; dir[1] = r.dir.y; dir[2] = r.dir.z;
+    return 1;
+}
+void rro_jitter(const float* dir, float spread, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t node, uint32_t stream, float* out) {
+    RngCtx rc{seed, pixel, sample};
+    V3 r = jitter(load3(dir), spread, rc, node, stream);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void rro_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out) { philox4x32_10(ctr, key, out); }
+void rro_chacha_block(const uint32_t* key, uint64_t counter, int rounds, uint32_t* out) { chacha_block(key, counter, rounds, out); }
+void rro_stdrng_u32(uint64_t seed, int n, uint32_t* out) { StdRng r(seed); for (int i = 0; i < n; i++) out[i] = r.next_u32(); }
+int rro_approx_equal(float a, float b) { return approx_equal(a, b) ? 1 : 0; }
+void rro_sincos(const float* x, int n, float* s, float* c) { for (int i = 0; i < n; i++) sincos_f32(x[i], &s[i], &c[i]); }
+void rro_acos(const float* x, int n, float* y) { for (int i = 0; i < n; i++) y[i] = acos_f32(x[i]); }
+void rro_atan2(const float* yy, const float* xx, int n, float* out) { for (int i = 0; i < n; i++) out[i] = atan2_f32(yy[i], xx[i]); }
+void rro_primary_ray(const rr_camera* cam, const rr_config* cfg, int x, int y, uint16_t xi, uint16_t yi, float* origin, float* dir) {
+    Ray r = make_primary(*cam, *cfg, x, y, xi, yi, cell_size_for(cfg->samples));
+    origin[0] = r.origin.x; origin[1] = r.origin.y; origin[2] = r.origin.z; dir[0] = r.dir.x; dir[1] = r.dir.y; dir[2] = r.dir.z;
+}
+// nearest-hit query of one mesh, BVH vs brute force (property tests)
+int rro_mesh_cast(const rr_flat_scene* fs, int mesh, const float* origin, const float* dir, int brute_force, float* toi, uint32_t* face_id) {
+    OScene sc; sc.fs = fs; sc.brute_force = brute_force != 0;
+    sc.accel.resize(fs->n_meshes);
+    if (!sc.brute_force) build_accel(fs->meshes[mesh], sc.accel[mesh]);
+    Ray r{load3(origin), load3(dir)};
+    MeshHit h;
+    if (!mesh_cast(sc, mesh, r, &h)) return 0;
+    *toi = h.toi; *face_id = h.face_id;
+    return 1;
+}
+
+} // extern "C"

@@ -1,0 +1,562 @@
+"""Host-side mirror of rustray's scene loading, ending in a FlatScene.
+
+This is the caller side of the hot path: it reproduces
+what `Scene::load` leaves in memory for the scene kinds whose assets exist
+offline — JSON scenes with spheres, planes, nested JSON and Wavefront OBJ
+meshes — so that fixtures and benchmarks feed the trace loop exactly the
+items, materials, lights and camera the reference would.
+
+Reference: src/scene.rs:121-157 (load), :159-641 (load_json), :1126-1367
+(load_wavefront), :1386-1401 (default light), :1426-1562 (auto camera / env),
+:1666-1688 (init / update); src/shape/mod.rs:138-299 (Material defaults and
+apply_diff), :708-729 (transform order), :769-772 (material cache);
+src/shape/mesh.rs:166-202, src/shape/sphere.rs:104-118.
+
+glTF loading (src/scene.rs:722-978) is not implemented in this round.
+"""
+from __future__ import annotations
+
+import copy
+import json
+import math
+import os
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from .camera import Camera, OBLIQUE_CAM_POS, DEFAULT_FOV_DEG, approx_equal
+from .flat import (FlatScene, Item, Light, Material, MeshData, RR_ITEM_MESH, RR_ITEM_SPHERE,
+                   RR_LIGHT_DIRECTIONAL, RR_LIGHT_POINT, RR_LIGHT_SPOT, TEX_NAMES)
+
+F32 = np.float32
+
+
+def _f32(v) -> float:
+    return float(np.float32(v))
+
+
+# ---------------------------------------------------------------------------
+# transforms (f32 arithmetic like nalgebra's Matrix4<f32>)
+# ---------------------------------------------------------------------------
+def get_transformation(trans, translation, scale, rotation):
+    """ShapeBasics::get_transformation (src/shape/mod.rs:708-729): trans * T * Rz * Ry * Rx * S."""
+    def rot(axis, a):
+        c, s = F32(math.cos(a)), F32(math.sin(a))
+        m = np.eye(4, dtype=F32)
+        if axis == 0:
+            m[1, 1], m[1, 2], m[2, 1], m[2, 2] = c, -s, s, c
+        elif axis == 1:
+            m[0, 0], m[0, 2], m[2, 0], m[2, 2] = c, s, -s, c
+        else:
+            m[0, 0], m[0, 1], m[1, 0], m[1, 1] = c, -s, s, c
+        return m
+    t = np.eye(4, dtype=F32)
+    t[:3, 3] = np.asarray(translation, dtype=F32)
+    s = np.diag(np.asarray(list(scale) + [1.0], dtype=F32))
+    m = np.asarray(trans, dtype=F32)
+    for f in (t, rot(2, F32(rotation[2])), rot(1, F32(rotation[1])), rot(0, F32(rotation[0])), s):
+        m = (m @ f).astype(F32)
+    return m
+
+
+def inverse_affine(m):
+    """ShapeBasics::calc_inverse (src/shape/mod.rs:763-767); computed in f64, rounded to f32."""
+    inv = np.linalg.inv(np.asarray(m, dtype=np.float64))
+    inv[3, :] = [0.0, 0.0, 0.0, 1.0]
+    return inv.astype(F32)
+
+
+class Shape:
+    """One scene item before flattening (ShapeBasics + payload)."""
+
+    def __init__(self, kind, name, material_id):
+        self.kind = kind
+        self.name = name
+        self.id = 0
+        self.material_id = material_id
+        self.visible = True
+        self.flip_normals = False
+        self.trans = np.eye(4, dtype=F32)
+        self.radius = 0.0
+        self.mesh: Optional[int] = None
+
+    def apply_transformation(self, translation, scale, rotation):
+        self.trans = get_transformation(self.trans, translation, scale, rotation)
+
+
+class Scene:
+    def __init__(self, root: str = "."):
+        """`root`: directory that scene-relative paths ("scene/...") resolve against."""
+        self.root = root
+        self.item_id = 0
+        self.cam = Camera()
+        self.items: List[Shape] = []
+        self.lights: List[Light] = []
+        self.materials: Dict[int, Material] = {}
+        self.material_tex_paths: Dict[int, Dict[int, str]] = {}
+        self.meshes: List[MeshData] = []
+        self.textures: List[np.ndarray] = []
+        self._tex_by_path: Dict[str, int] = {}
+        self._mesh_by_key: Dict[str, int] = {}
+        # RaytracingConfig fields a JSON "config" block may override (src/scene.rs:180-198)
+        self.raytracing_config: Dict[str, object] = {}
+        self.name = ""
+
+    # ---- ids ---------------------------------------------------------------
+    def get_next_id(self) -> int:
+        self.item_id += 1
+        return self.item_id
+
+    # ---- textures ------------------------------------------------------------
+    def _path(self, p: str) -> str:
+        return p if os.path.isabs(p) else os.path.join(self.root, p)
+
+    def load_texture(self, path: str) -> int:
+        """Material::load_texture (src/shape/mod.rs:378-418): decoded to RGBA8.  PIL's decoders stand
+        in for the `image` crate; fixtures therefore store the DECODED pixels."""
+        full = self._path(path)
+        key = os.path.normpath(full)
+        if key in self._tex_by_path:
+            return self._tex_by_path[key]
+        from PIL import Image
+        im = Image.open(full)
+        im = im.convert("RGBA")
+        arr = np.ascontiguousarray(np.asarray(im, dtype=np.uint8))
+        self.textures.append(arr)
+        self._tex_by_path[key] = len(self.textures) - 1
+        return self._tex_by_path[key]
+
+    # ---- top-level load (src/scene.rs:121-157) ------------------------------------
+    def load(self, path: str) -> List[int]:
+        ext = os.path.splitext(path)[1].lower()
+        if ext == ".json":
+            ids = self.load_json(path)
+        elif ext == ".obj":
+            ids = self.load_wavefront(path)
+        else:
+            raise NotImplementedError(f"cannot load {path} (glTF loading is not implemented)")
+        return ids
+
+    # ---- JSON (src/scene.rs:159-641) -------------------------------------------------
+    @staticmethod
+    def _xyz(obj, key, default):
+        if obj is None or not isinstance(obj, dict):
+            return tuple(default)
+        v = obj.get(key)
+        if isinstance(v, dict) and all(v.get(k) is not None for k in "xyz"):
+            return (_f32(v["x"]), _f32(v["y"]), _f32(v["z"]))
+        return tuple(default)
+
+    @staticmethod
+    def _rgb(obj, key, default):
+        if obj is None or not isinstance(obj, dict):
+            return tuple(default)
+        v = obj.get(key)
+        if isinstance(v, dict) and all(v.get(k) is not None for k in "rgb"):
+            return (_f32(v["r"]), _f32(v["g"]), _f32(v["b"]))
+        return tuple(default)
+
+    def load_json(self, path: str) -> List[int]:
+        loaded: List[int] = []
+        with open(self._path(path), "r") as f:
+            data = json.load(f)
+        if not self.name:
+            self.name = str(data.get("name", ""))
+        config = data.get("config")
+        if config:
+            for k in ("monte_carlo", "samples", "focal_length", "aperture_size", "fog_density",
+                      "max_recursion", "gamma_correction"):
+                if config.get(k) is not None:
+                    self.raytracing_config[k] = config[k]
+            if config.get("fog_color") is not None:
+                fc = config["fog_color"]
+                self.raytracing_config["fog_color"] = (_f32(fc["r"]), _f32(fc["g"]), _f32(fc["b"]))
+        camera = data.get("camera")
+        if camera:
+            self.cam.eye_pos = np.asarray(self._xyz(camera, "pos", (0.0, 0.0, 0.0)))
+            self.cam.up = np.asarray(self._xyz(camera, "up", (0.0, 1.0, 0.0)))
+            self.cam.dir = np.asarray(self._xyz(camera, "dir", (0.0, 0.0, -1.0)))
+            if camera.get("fov") is not None:
+                self.cam.fov = _f32(math.radians(float(camera["fov"])))
+            if camera.get("z_near") is not None:
+                self.cam.clipping_near = _f32(camera["z_near"])
+            if camera.get("z_far") is not None:
+                self.cam.clipping_far = _f32(camera["z_far"])
+        for light in data.get("lights") or []:
+            max_angle = _f32(F32(math.pi) / F32(2.0))
+            if light.get("max_angle") is not None:
+                max_angle = _f32(math.radians(_f32(light["max_angle"])))
+            lt = {"point": RR_LIGHT_POINT, "directional": RR_LIGHT_DIRECTIONAL, "spot": RR_LIGHT_SPOT}.get(
+                light["light_type"], RR_LIGHT_POINT)
+            self.get_next_id()
+            self.lights.append(Light(pos=self._xyz(light, "pos", (0.0, 0.0, 0.0)),
+                                     dir=self._xyz(light, "dir", (0.0, -1.0, 0.0)),
+                                     color=self._rgb(light, "color", (0.0, 0.0, 0.0)),
+                                     intensity=_f32(light["intensity"]), max_angle=max_angle, light_type=lt))
+        for obj in data.get("objects") or []:
+            mat_id = self.get_next_id()
+            material = Material()
+            tex_paths: Dict[int, str] = {}
+            item_type = obj["type"]
+            name = obj.get("name") if obj.get("name") is not None else "unknown"
+            colors = obj.get("color")
+            if colors:
+                material.base_color = self._rgb(colors, "base", material.base_color)
+                material.specular_color = self._rgb(colors, "specular", material.specular_color)
+                spec = colors.get("specular")
+                if isinstance(spec, dict) and isinstance(spec.get("factor"), float):
+                    material.specular_color = tuple(_f32(F32(c) * F32(spec["factor"])) for c in material.base_color)
+                material.ambient_color = self._rgb(colors, "ambient", material.ambient_color)
+                amb = colors.get("ambient")
+                if isinstance(amb, dict) and isinstance(amb.get("factor"), float):
+                    material.ambient_color = tuple(_f32(F32(c) * F32(amb["factor"])) for c in material.base_color)
+            for k in ("alpha", "shininess", "reflectivity", "refraction_index", "normal_map_strength",
+                      "shadow_softness", "roughness"):
+                if obj.get(k) is not None:
+                    setattr(material, k, _f32(obj[k]))
+            for k in ("texture_filtering_nearest", "cast_shadow", "receive_shadow", "monte_carlo",
+                      "smooth_shading", "reflection_only", "backface_cullig"):
+                if obj.get(k) is not None:
+                    setattr(material, k, bool(obj[k]))
+            texture = obj.get("texture")
+            if texture:
+                # src/scene.rs:351-397: the JSON loader knows these seven keys (no "reflectivity")
+                for key in ("base", "ambient", "specular", "normal", "alpha", "roughness", "ambient_occlusion"):
+                    if isinstance(texture.get(key), str):
+                        slot = TEX_NAMES.index(key)
+                        material.texture[slot] = self.load_texture(texture[key])
+                        tex_paths[slot] = texture[key]
+            visible = bool(obj["visible"]) if obj.get("visible") is not None else True
+            flip_normals = bool(obj["flip_normals"]) if obj.get("flip_normals") is not None else False
+            rotation, scale, translation = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0)
+            tr = obj.get("transformation")
+            if tr:
+                scale = self._xyz(tr, "scale", scale)
+                translation = self._xyz(tr, "translation", translation)
+                rotation = self._xyz(tr, "rotation", rotation)
+                rotation = tuple(_f32(math.radians(r)) for r in rotation)
+            shape: Optional[Shape] = None
+            if item_type == "sphere":
+                pos = self._xyz(obj, "pos", (0.0, 0.0, 0.0))
+                radius = _f32(obj["radius"]) if obj.get("radius") is not None else 0.0
+                shape = Shape(RR_ITEM_SPHERE, name, mat_id)
+                shape.radius = radius
+                shape.trans[:3, 3] = np.asarray(pos, dtype=F32)  # Sphere::new_with_pos
+                shape.id = self.get_next_id()
+                loaded.append(shape.id)
+            elif item_type == "plane":
+                v = obj["vertices"]
+                pts = np.asarray([[_f32(p["x"]), _f32(p["y"]), _f32(p["z"])] for p in v[:4]], dtype=F32)
+                md = MeshData(positions=pts, indices=np.asarray([[0, 1, 2], [0, 2, 3]], np.uint32),
+                              uvs=np.asarray([[0, 0], [1, 0], [1, 1], [0, 1]], F32),
+                              uv_indices=np.asarray([[0, 1, 2], [0, 2, 3]], np.uint32))
+                self.meshes.append(md)
+                shape = Shape(RR_ITEM_MESH, name, mat_id)
+                shape.mesh = len(self.meshes) - 1
+                shape.id = self.get_next_id()
+                loaded.append(shape.id)
+            elif item_type in ("wavefront", "json", "gltf"):
+                path = obj["path"]
+                if item_type == "wavefront":
+                    ids = self.load_wavefront(path)
+                elif item_type == "json":
+                    ids = self.load_json(path)
+                else:
+                    raise NotImplementedError("glTF loading is not implemented (asset: %s)" % path)
+                for item in self.items:
+                    if item.id in ids:
+                        if obj.get("name") is not None:
+                            item.name = name
+                        self._apply_diff(item.material_id, material, tex_paths)
+                        item.visible = visible
+                        item.flip_normals = flip_normals
+                        item.apply_transformation(translation, scale, rotation)
+                loaded.extend(ids)
+            if shape is not None:
+                shape.visible = visible
+                shape.flip_normals = flip_normals
+                shape.apply_transformation(translation, scale, rotation)
+                shape.id = self.get_next_id()  # src/scene.rs:541 (ids are assigned twice)
+                self.items.append(shape)
+                self.materials[mat_id] = material
+                self.material_tex_paths[mat_id] = tex_paths
+        return loaded
+
+    def _apply_diff(self, target_id: int, new_mat: Material, new_tex: Dict[int, str]) -> None:
+        """Material::apply_diff (src/shape/mod.rs:182-299): copy fields that differ from the defaults."""
+        tgt = self.materials[target_id]
+        d = Material()
+        for k in ("ambient_color", "base_color", "specular_color"):
+            if any(not approx_equal(a, b) for a, b in zip(getattr(d, k), getattr(new_mat, k))):
+                setattr(tgt, k, getattr(new_mat, k))
+        for k in Material._FLOATS:
+            if not approx_equal(getattr(d, k), getattr(new_mat, k)):
+                setattr(tgt, k, getattr(new_mat, k))
+        for k in Material._BOOLS:
+            if getattr(d, k) != getattr(new_mat, k):
+                setattr(tgt, k, getattr(new_mat, k))
+        for slot in range(len(TEX_NAMES)):
+            if new_mat.texture[slot] >= 0:
+                tgt.texture[slot] = new_mat.texture[slot]
+
+    # ---- Wavefront OBJ (src/scene.rs:1126-1367; tobj 4 with triangulate + single_index) ----
+    def load_wavefront(self, path: str) -> List[int]:
+        loaded: List[int] = []
+        full = self._path(path)
+        models, mtl_names = _parse_obj(full)
+        mtl = _parse_mtl(os.path.join(os.path.dirname(full), mtl_names[0])) if mtl_names else {}
+        double_check: Dict[str, int] = {}
+        for mi, m in enumerate(models):
+            if len(m["positions"]) == 0:
+                continue
+            mat_name = m["material"]
+            if mat_name is not None and mat_name in mtl:
+                if mat_name in double_check:
+                    material_id = double_check[mat_name]
+                else:
+                    material_id = self.get_next_id()
+                    mat = Material()
+                    tm = mtl[mat_name]
+                    if "Ns" in tm: mat.shininess = _f32(tm["Ns"][0])
+                    if "Ka" in tm: mat.ambient_color = tuple(_f32(v) for v in tm["Ka"][:3])
+                    if "Ks" in tm: mat.specular_color = tuple(_f32(v) for v in tm["Ks"][:3])
+                    if "Kd" in tm: mat.base_color = tuple(_f32(v) for v in tm["Kd"][:3])
+                    if "Ni" in tm: mat.refraction_index = _f32(tm["Ni"][0])
+                    if "d" in tm: mat.alpha = _f32(tm["d"][0])
+                    mat.ambient_color = tuple(_f32(F32(c) * F32(0.01)) for c in mat.base_color)  # :1284
+                    if "illum" in tm and int(tm["illum"][0]) > 2:
+                        mat.reflectivity = 0.5
+                    tex_paths = {}
+                    for key, slot in (("map_Kd", 0), ("map_Bump", 3), ("map_bump", 3), ("bump", 3),
+                                      ("map_Ka", 1), ("map_Ks", 2), ("map_d", 4)):
+                        if key in tm:
+                            tp = tm[key][-1]
+                            if not os.path.isabs(tp):
+                                tp = os.path.join(os.path.dirname(path), tp)
+                            mat.texture[slot] = self.load_texture(tp)
+                            tex_paths[slot] = tp
+                    self.materials[material_id] = mat
+                    self.material_tex_paths[material_id] = tex_paths
+                    double_check[mat_name] = material_id
+            else:
+                material_id = self.get_next_id()
+                self.materials[material_id] = Material()
+                self.material_tex_paths[material_id] = {}
+            pos = np.asarray(m["positions"], dtype=F32).reshape(-1, 3)
+            idx = np.asarray(m["indices"], dtype=np.uint32).reshape(-1, 3)
+            uvs = np.asarray(m["texcoords"], dtype=F32).reshape(-1, 2)
+            nrm = np.asarray(m["normals"], dtype=F32).reshape(-1, 3)
+            md = MeshData(positions=pos, indices=idx, uvs=uvs,
+                          uv_indices=idx.copy() if len(uvs) else np.zeros((0, 3), np.uint32),
+                          normals=nrm,
+                          normal_indices=idx.copy() if len(nrm) else np.zeros((0, 3), np.uint32))
+            key = f"{os.path.normpath(full)}#{mi}"
+            if key in self._mesh_by_key:
+                mesh_index = self._mesh_by_key[key]
+            else:
+                self.meshes.append(md)
+                mesh_index = len(self.meshes) - 1
+                self._mesh_by_key[key] = mesh_index
+            item = Shape(RR_ITEM_MESH, m["name"], material_id)
+            item.mesh = mesh_index
+            item.id = self.get_next_id()
+            loaded.append(item.id)
+            self.items.append(item)
+        return loaded
+
+    # ---- defaults (src/scene.rs:1386-1401, :1426-1562) ------------------------------------
+    def add_default_light(self) -> None:
+        self.get_next_id()
+        self.lights.append(Light(pos=(-2.0, 10.0, 5.0), dir=(0.0, -1.0, 0.0), color=(1.0, 1.0, 1.0),
+                                 intensity=200.0, max_angle=_f32(F32(math.pi) / F32(2.0)),
+                                 light_type=RR_LIGHT_POINT))
+
+    def _local_bbox(self, it: Shape):
+        if it.kind == RR_ITEM_SPHERE:
+            r = it.radius
+            return (-r, -r, -r), (r, r, r)
+        p = self.meshes[it.mesh].positions
+        return tuple(p.min(axis=0).tolist()), tuple(p.max(axis=0).tolist())
+
+    def _world_bbox_points(self) -> np.ndarray:
+        pts = []
+        for it in self.items:
+            lo, hi = self._local_bbox(it)
+            for cx in (lo[0], hi[0]):
+                for cy in (lo[1], hi[1]):
+                    for cz in (lo[2], hi[2]):
+                        pts.append((it.trans.astype(np.float64) @ np.array([cx, cy, cz, 1.0]))[:3])
+        return np.asarray(pts)
+
+    def find_optimal_camera_pos(self) -> None:
+        pts = self._world_bbox_points()
+        mn, mx = pts.min(axis=0), pts.max(axis=0)
+        center = mn + np.abs(mx - mn) / 2.0
+        direction = np.asarray(OBLIQUE_CAM_POS) / np.linalg.norm(OBLIQUE_CAM_POS)
+        factor, inc = F32(0.0), F32(0.01)
+        self.cam.dir = -direction
+        while factor < F32(1000.0):
+            self.cam.eye_pos = center + direction * float(factor)
+            self.cam.init_matrices()
+            if self.cam.points_in_frustum(pts):
+                self.cam.eye_pos = self.cam.eye_pos + direction * 1.001
+                break
+            factor = F32(factor + inc)
+        fov = F32(0.0)
+        while fov < F32(DEFAULT_FOV_DEG):
+            self.cam.fov = _f32(math.radians(float(fov)))
+            if float(fov) > 0.0:
+                self.cam.init_matrices()
+                if self.cam.points_in_frustum(pts):
+                    self.cam.fov = _f32(F32(self.cam.fov) * F32(1.1))
+                    break
+            fov = F32(fov + inc)
+        self.cam.init_matrices()
+
+    def find_and_set_default_env_if_needed(self) -> None:
+        if self.cam.is_default_cam():
+            self.find_optimal_camera_pos()
+        if len(self.lights) == 0:
+            self.add_default_light()
+
+    # ---- flatten --------------------------------------------------------------------
+    @staticmethod
+    def _cache_of(m: Material) -> Material:
+        """ShapeBasics::update_material_cache (src/shape/mod.rs:769-772): defaults + apply_diff_without_textures."""
+        c, d = Material(), Material()
+        for k in ("ambient_color", "base_color", "specular_color"):
+            if any(not approx_equal(a, b) for a, b in zip(getattr(d, k), getattr(m, k))):
+                setattr(c, k, getattr(m, k))
+        for k in Material._FLOATS:
+            if not approx_equal(getattr(d, k), getattr(m, k)):
+                setattr(c, k, getattr(m, k))
+        for k in Material._BOOLS:
+            if getattr(d, k) != getattr(m, k):
+                setattr(c, k, getattr(m, k))
+        return c
+
+    def flatten(self) -> FlatScene:
+        fs = FlatScene()
+        fs.name = self.name
+        fs.textures = list(self.textures)
+        fs.meshes = list(self.meshes)
+        fs.lights = copy.deepcopy(self.lights)
+        mat_index: Dict[int, int] = {}
+        for mid, m in self.materials.items():
+            mat_index[mid] = len(fs.materials)
+            fs.materials.append(copy.deepcopy(m))
+        cache_index: Dict[int, int] = {}
+        for it in self.items:
+            if it.material_id not in cache_index:
+                cache_index[it.material_id] = len(fs.materials)
+                fs.materials.append(self._cache_of(self.materials[it.material_id]))
+            lo, hi = self._local_bbox(it)
+            fs.items.append(Item(kind=it.kind, id=it.id, material=mat_index[it.material_id],
+                                 material_cache=cache_index[it.material_id],
+                                 mesh=it.mesh if it.mesh is not None else -1, radius=it.radius,
+                                 trans=it.trans.copy(), trans_inv=inverse_affine(it.trans),
+                                 bbox_min=lo, bbox_max=hi, visible=it.visible, flip_normals=it.flip_normals,
+                                 name=it.name))
+        return fs
+
+
+def load_scene(paths, width: int, height: int, root: str = ".") -> Scene:
+    """What Run::init_scene does in cmd mode (reference src/run.rs:196-244): load every scene file,
+    init the camera for the frame size, add the default camera/light if needed."""
+    sc = Scene(root)
+    for p in ([paths] if isinstance(paths, str) else paths):
+        sc.load(p)
+    sc.cam.init(width, height)
+    sc.find_and_set_default_env_if_needed()
+    return sc
+
+
+# ---------------------------------------------------------------------------
+# OBJ / MTL parsing with tobj's triangulate + single_index behaviour
+# ---------------------------------------------------------------------------
+def _parse_mtl(path: str) -> Dict[str, dict]:
+    mats: Dict[str, dict] = {}
+    cur = None
+    if not os.path.exists(path):
+        return mats
+    with open(path, "r", errors="replace") as f:
+        for line in f:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            if t[0] == "newmtl":
+                cur = {}
+                mats[" ".join(t[1:])] = cur
+            elif cur is not None:
+                if t[0].startswith("map_") or t[0] in ("bump", "norm"):
+                    cur[t[0]] = t[1:]
+                else:
+                    try:
+                        cur[t[0]] = [float(v) for v in t[1:]]
+                    except ValueError:
+                        cur[t[0]] = t[1:]
+    return mats
+
+
+def _parse_obj(path: str):
+    v, vt, vn = [], [], []
+    models = []
+    mtl_names = []
+
+    def new_model(name):
+        return {"name": name, "material": None, "positions": [], "normals": [], "texcoords": [],
+                "indices": [], "_map": {}, "_faces": 0}
+    cur = new_model("unnamed_object")
+
+    def fix(i, n):
+        i = int(i)
+        return i - 1 if i > 0 else n + i
+
+    def vert(tok):
+        parts = tok.split("/")
+        pi = fix(parts[0], len(v))
+        ti = fix(parts[1], len(vt)) if len(parts) > 1 and parts[1] else -1
+        ni = fix(parts[2], len(vn)) if len(parts) > 2 and parts[2] else -1
+        key = (pi, ti, ni)
+        m = cur["_map"]
+        if key not in m:
+            m[key] = len(cur["positions"]) // 3
+            cur["positions"].extend(v[pi])
+            if ti >= 0:
+                cur["texcoords"].extend(vt[ti])
+            if ni >= 0:
+                cur["normals"].extend(vn[ni])
+        return m[key]
+
+    with open(path, "r", errors="replace") as f:
+        for line in f:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            k = t[0]
+            if k == "v":
+                v.append([float(t[1]), float(t[2]), float(t[3])])
+            elif k == "vt":
+                vt.append([float(t[1]), float(t[2]) if len(t) > 2 else 0.0])
+            elif k == "vn":
+                vn.append([float(t[1]), float(t[2]), float(t[3])])
+            elif k == "f":
+                ids = [vert(tok) for tok in t[1:]]
+                for i in range(1, len(ids) - 1):
+                    cur["indices"].extend([ids[0], ids[i], ids[i + 1]])
+                cur["_faces"] += 1
+            elif k in ("o", "g"):
+                if cur["_faces"] > 0:
+                    models.append(cur)
+                cur = new_model(" ".join(t[1:]) if len(t) > 1 else "unnamed_object")
+            elif k == "usemtl":
+                name = " ".join(t[1:])
+                if cur["_faces"] > 0 and cur["material"] != name:
+                    models.append(cur)
+                    cur = new_model(cur["name"])
+                cur["material"] = name
+            elif k == "mtllib":
+                mtl_names.append(" ".join(t[1:]))
+    if cur["_faces"] > 0:
+        models.append(cur)
+    return models, mtl_names
