@@ -1,0 +1,183 @@
+"""ctypes binding of librustray_hip.so (the C ABI of include/rustray_hip.h).
+
+This is the only way Python reaches the trace loop: there is no CPU or PyTorch
+fallback.  If the HIP library has not been built, or no GPU is present, the
+calls below raise — they never silently compute something else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .flat import (rr_camera, rr_config, rr_flat_scene, rr_frame, rr_frame_stats, rr_pick_result, rr_region)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librustray_hip.so")
+_LIB = None
+
+EXPORTS = ["rr_device_count", "rr_last_error", "rr_scene_create", "rr_scene_destroy", "rr_scene_update_transforms",
+           "rr_sample_table", "rr_render", "rr_region_pixel_count", "rr_render_region_device",
+           "rr_deinterleave_device", "rr_pick", "rr_scene_last_stats"]
+
+
+class RustrayHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"rustray_hip error {code}: {msg}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile librustray_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["make", "-C", csrc], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `make -C rustray_amd/csrc` — there is no fallback path")
+        L = C.CDLL(LIB_PATH)
+        L.rr_last_error.restype = C.c_char_p
+        L.rr_region_pixel_count.restype = C.c_uint64
+        L.rr_region_pixel_count.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(rr_region)]
+        L.rr_scene_create.argtypes = [C.POINTER(rr_flat_scene), C.c_int, C.POINTER(C.c_void_p)]
+        L.rr_scene_destroy.argtypes = [C.c_void_p]
+        L.rr_scene_destroy.restype = None
+        L.rr_scene_update_transforms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rr_sample_table.argtypes = [C.c_uint16, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.rr_render.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p, C.POINTER(rr_frame), C.c_void_p]
+        L.rr_render_region_device.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p,
+                                              C.POINTER(rr_region), C.POINTER(rr_frame), C.c_void_p, C.c_void_p]
+        L.rr_deinterleave_device.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.rr_pick.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.c_int, C.c_int, C.POINTER(rr_pick_result)]
+        L.rr_scene_last_stats.argtypes = [C.c_void_p, C.POINTER(rr_frame_stats)]
+        L.rr_scene_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.rr_math_probe.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_uint64, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise RustrayHipError(rc, lib().rr_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    return int(lib().rr_device_count())
+
+
+def sample_table(samples: int):
+    """Built-in sub-sample table of the library (reference src/raytracing.rs:290-313)."""
+    xy = np.zeros((max(samples, 1), 2), np.uint16)
+    cs = C.c_uint32(0)
+    _check(lib().rr_sample_table(C.c_uint16(samples), xy.ctypes.data_as(C.c_void_p), C.byref(cs)))
+    return xy[:samples], int(cs.value)
+
+
+def region_pixel_count(width: int, height: int, tile_w: int, tile_h: int, n_ranks: int, rank: int) -> int:
+    rg = rr_region(tile_w, tile_h, n_ranks, rank)
+    return int(lib().rr_region_pixel_count(width, height, C.byref(rg)))
+
+
+def _sxy(sample_xy):
+    if sample_xy is None:
+        return None, None
+    a = np.ascontiguousarray(sample_xy, np.uint16)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceScene:
+    """Owns one `rr_scene*` (scene uploaded to one GPU, acceleration structures built)."""
+
+    def __init__(self, flat_scene, device: int = 0):
+        self._h = C.c_void_p(None)
+        self.device = device
+        self._flat = flat_scene               # keeps host arrays alive during the call
+        fs = flat_scene.c_struct() if hasattr(flat_scene, "c_struct") else flat_scene
+        _check(lib().rr_scene_create(C.byref(fs), device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().rr_scene_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- whole frame into host arrays -------------------------------------------
+    def render(self, cam: rr_camera, cfg: rr_config, sample_xy=None, aux: bool = True):
+        w, h = cam.width, cam.height
+        rgba = np.zeros((h, w, 4), np.uint8)
+        out = dict(rgba=rgba)
+        fr = rr_frame(rgba.ctypes.data, None, None, None)
+        if aux:
+            out["normal"] = np.zeros((h, w, 3), np.float32)
+            out["depth"] = np.zeros((h, w), np.float32)
+            out["object_id"] = np.zeros((h, w), np.uint32)
+            fr = rr_frame(rgba.ctypes.data, out["normal"].ctypes.data, out["depth"].ctypes.data, out["object_id"].ctypes.data)
+        keep, p = _sxy(sample_xy)
+        _check(lib().rr_render(self._h, C.byref(cam), C.byref(cfg), p, C.byref(fr), None))
+        return out
+
+    # -- one rank's region into device (torch) tensors ----------------------------
+    def render_region_device(self, cam, cfg, region: rr_region, out_ptrs, stream_ptr=None, sample_xy=None):
+        """out_ptrs: (rgba8, normal, depth, object_id) device pointers (ints, None allowed for aux)."""
+        fr = rr_frame(*[C.c_void_p(p) if p else None for p in out_ptrs])
+        keep, p = _sxy(sample_xy)
+        _check(lib().rr_render_region_device(self._h, C.byref(cam), C.byref(cfg), p, C.byref(region), C.byref(fr),
+                                             C.c_void_p(stream_ptr) if stream_ptr else None, None))
+
+    def update_transforms(self, trans: np.ndarray, trans_inv: np.ndarray):
+        """trans / trans_inv: (n_items, 4, 4) in math layout."""
+        t = np.ascontiguousarray(np.transpose(np.asarray(trans, np.float32), (0, 2, 1)))
+        ti = np.ascontiguousarray(np.transpose(np.asarray(trans_inv, np.float32), (0, 2, 1)))
+        _check(lib().rr_scene_update_transforms(self._h, t.ctypes.data_as(C.c_void_p), ti.ctypes.data_as(C.c_void_p)))
+
+    def pick(self, cam: rr_camera, x: int, y: int) -> rr_pick_result:
+        r = rr_pick_result()
+        _check(lib().rr_pick(self._h, C.byref(cam), x, y, C.byref(r)))
+        return r
+
+    def set_profiling(self, on: bool):
+        _check(lib().rr_scene_set_profiling(self._h, 1 if on else 0))
+
+    def stats(self) -> dict:
+        st = rr_frame_stats()
+        _check(lib().rr_scene_last_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in rr_frame_stats._fields_}
+
+
+def deinterleave_device(width, height, tile_w, tile_h, n_ranks, elem_bytes, src_ptr, dst_ptr, device, stream_ptr=None):
+    _check(lib().rr_deinterleave_device(width, height, tile_w, tile_h, n_ranks, elem_bytes, C.c_void_p(src_ptr),
+                                        C.c_void_p(dst_ptr), device, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+
+def math_probe(op: int, a, b=None, c=None, seed: int = 0, device: int = 0):
+    a = np.ascontiguousarray(a, np.float32)
+    n = len(a)
+    b = np.ascontiguousarray(b, np.float32) if b is not None else None
+    c = np.ascontiguousarray(c, np.float32) if c is not None else None
+    outs = [np.zeros(n, np.float32) for _ in range(3)]
+    _check(lib().rr_math_probe(op, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p) if b is not None else None,
+                               c.ctypes.data_as(C.c_void_p) if c is not None else None, n,
+                               *[o.ctypes.data_as(C.c_void_p) for o in outs], C.c_uint64(seed), device))
+    return outs

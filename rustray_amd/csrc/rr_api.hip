@@ -1,0 +1,913 @@
+// rr_api.hip — host side of librustray_hip.so: the C ABI of include/rustray_hip.h.
+//
+// Replaces the frame loop of `RendererManager::start` (reference
+// src/renderer.rs:105-172): instead of a shuffled queue of 2x2-pixel cells and
+// num_cpus-2 worker threads calling Raytracing::render per pixel, one call
+// uploads the frame constants and drives the wavefront kernels of
+// rr_kernels.hip over batches of primary samples.
+#include "../../include/rustray_hip.h"
+#include "rr_bvh.h"
+#include "rr_device.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rr_kernels.hip"
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string tl_error;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    tl_error = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? RR_ERR_OUT_OF_MEMORY : RR_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// device buffer helper
+// ---------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct TimedLaunch { hipEvent_t a, b; int kind; };
+
+struct rr_scene {
+    int device = 0;
+    int n_cus = 256;
+    std::mutex mu;
+    // scene data
+    DevBuf items, nodes, tris, attrs, face_slot, materials, textures, texels, lights;
+    DSceneView view{};
+    std::vector<DItem> h_items;
+    std::vector<uint32_t> item_mesh; // mesh index per item (or ~0u)
+    std::vector<float> mesh_lo, mesh_hi; // unused placeholders for future refits
+    uint32_t n_enabled_lights = 0;
+    uint32_t tlas_node_capacity = 0;
+    // frame state (grown on demand, reused across frames)
+    DevBuf q[2][4];   // r0 r1 r2 hit
+    size_t q_cap[2] = {0, 0};
+    DevBuf sq[4];
+    size_t sq_cap = 0;
+    DevBuf acc_rgb, acc_normal, acc_depth, acc_id;
+    DevBuf region_xy, sample_xy, pool, counters;
+    DevBuf tmp_out[4];
+    std::vector<uint32_t> h_region_xy;
+    rr_region region_cached{0, 0, 0, 0};
+    uint32_t region_w = 0, region_h = 0;
+    // stats
+    rr_frame_stats stats{};
+    bool profiling = false;
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> event_pool;
+    hipEvent_t frame_a = nullptr, frame_b = nullptr;
+};
+
+static const uint32_t POOL_WORDS = 16384;
+
+// ---------------------------------------------------------------------------
+// the reference's sub-sample table: StdRng::seed_from_u64(0) + shuffle + truncate
+// (reference src/raytracing.rs:290-313; rand 0.8: ChaCha12 core, PCG32 seed
+// expansion, Fisher-Yates from the back with widening-multiply rejection)
+// ---------------------------------------------------------------------------
+namespace {
+
+inline uint32_t rotl(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
+
+struct ChaCha12 {
+    uint32_t key[8];
+    uint64_t counter = 0;
+    uint32_t block[16];
+    int pos = 16;
+    explicit ChaCha12(uint64_t seed) {
+        uint64_t state = seed;
+        for (int i = 0; i < 8; i++) { // SeedableRng::seed_from_u64
+            state = state * 6364136223846793005ull + 11634580027462260723ull;
+            uint32_t xs = (uint32_t)(((state >> 18) ^ state) >> 27);
+            uint32_t rot = (uint32_t)(state >> 59);
+            key[i] = (xs >> rot) | (xs << ((32u - rot) & 31u));
+        }
+    }
+    void refill() {
+        uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
+                           key[4], key[5], key[6], key[7], (uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+        uint32_t x[16];
+        memcpy(x, in, sizeof x);
+        auto qr = [&](int a, int b, int c, int d) {
+            x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16);
+            x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);
+            x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);
+            x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+        };
+        for (int r = 0; r < 6; r++) { // 12 rounds = 6 double rounds
+            qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+            qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+        }
+        for (int i = 0; i < 16; i++) block[i] = x[i] + in[i];
+        counter++;
+        pos = 0;
+    }
+    uint32_t next_u32() { if (pos >= 16) refill(); return block[pos++]; }
+    uint32_t below(uint32_t range) { // UniformInt<u32>::sample_single(0, range)
+        uint32_t zone = (range << __builtin_clz(range)) - 1u;
+        for (;;) {
+            uint64_t m = (uint64_t)next_u32() * range;
+            if ((uint32_t)m <= zone) return (uint32_t)(m >> 32);
+        }
+    }
+};
+
+uint32_t cell_size_of(uint16_t samples) {
+    if (samples <= 1) return 1;
+    uint16_t v = (uint16_t)(samples + 2);
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p / 2;
+}
+
+} // namespace
+
+extern "C" int rr_sample_table(uint16_t samples, uint16_t* xy_out, uint32_t* cell_size_out) {
+    if (!xy_out && samples) return fail(RR_ERR_INVALID_ARGUMENT, "rr_sample_table: xy_out is NULL");
+    uint32_t cs = cell_size_of(samples);
+    std::vector<uint32_t> cells((size_t)cs * cs);
+    size_t k = 0;
+    for (uint32_t xi = 0; xi < cs; xi++)
+        for (uint32_t yi = 0; yi < cs; yi++) cells[k++] = xi | (yi << 16);
+    ChaCha12 rng(0);
+    for (size_t i = cells.size(); i-- > 1;) std::swap(cells[i], cells[rng.below((uint32_t)(i + 1))]);
+    for (uint32_t s = 0; s < samples && s < cells.size(); s++) {
+        xy_out[2 * s] = (uint16_t)(cells[s] & 0xffffu);
+        xy_out[2 * s + 1] = (uint16_t)(cells[s] >> 16);
+    }
+    if (cell_size_out) *cell_size_out = cs;
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// misc entry points
+// ---------------------------------------------------------------------------
+extern "C" int rr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" const char* rr_last_error(void) { return tl_error.c_str(); }
+
+static void fill_region(uint32_t w, uint32_t h, const rr_region& rg, std::vector<uint32_t>* xy) {
+    xy->clear();
+    uint32_t tx = (w + rg.tile_w - 1) / rg.tile_w, ty = (h + rg.tile_h - 1) / rg.tile_h;
+    for (uint32_t t = rg.rank; t < tx * ty; t += rg.n_ranks) {
+        uint32_t x0 = (t % tx) * rg.tile_w, y0 = (t / tx) * rg.tile_h;
+        uint32_t x1 = std::min(x0 + rg.tile_w, w), y1 = std::min(y0 + rg.tile_h, h);
+        for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t x = x0; x < x1; x++) xy->push_back(x | (y << 16));
+    }
+}
+static int check_region(uint32_t w, uint32_t h, const rr_region* rg) {
+    if (!rg) return fail(RR_ERR_INVALID_ARGUMENT, "region is NULL");
+    if (rg->tile_w == 0 || rg->tile_h == 0 || rg->n_ranks == 0 || rg->rank >= rg->n_ranks)
+        return fail(RR_ERR_INVALID_ARGUMENT, "bad region: tile %ux%u rank %u of %u", rg->tile_w, rg->tile_h, rg->rank, rg->n_ranks);
+    if (w == 0 || h == 0 || w > 65535u || h > 65535u) return fail(RR_ERR_INVALID_ARGUMENT, "bad frame size %ux%u", w, h);
+    return RR_OK;
+}
+extern "C" uint64_t rr_region_pixel_count(uint32_t width, uint32_t height, const rr_region* rg) {
+    if (check_region(width, height, rg) != RR_OK) return 0;
+    uint32_t tx = (width + rg->tile_w - 1) / rg->tile_w, ty = (height + rg->tile_h - 1) / rg->tile_h;
+    uint64_t n = 0;
+    for (uint32_t t = rg->rank; t < tx * ty; t += rg->n_ranks) {
+        uint32_t x0 = (t % tx) * rg->tile_w, y0 = (t / tx) * rg->tile_h;
+        n += (uint64_t)(std::min(x0 + rg->tile_w, width) - x0) * (std::min(y0 + rg->tile_h, height) - y0);
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------
+// scene validation + upload
+// ---------------------------------------------------------------------------
+static bool finite16(const float* m) { for (int i = 0; i < 16; i++) if (!std::isfinite(m[i])) return false; return true; }
+
+static int validate_scene(const rr_flat_scene* fs) {
+    if (!fs) return fail(RR_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (fs->abi_version != RR_ABI_VERSION) return fail(RR_ERR_INVALID_ARGUMENT, "abi_version %u, library speaks %u", fs->abi_version, RR_ABI_VERSION);
+    if ((fs->n_items && !fs->items) || (fs->n_meshes && !fs->meshes) || (fs->n_materials && !fs->materials) ||
+        (fs->n_textures && !fs->textures) || (fs->n_lights && !fs->lights))
+        return fail(RR_ERR_INVALID_ARGUMENT, "array pointer is NULL with a non-zero count");
+    for (uint32_t i = 0; i < fs->n_textures; i++) {
+        const rr_texture& t = fs->textures[i];
+        if ((uint64_t)t.width * t.height > 0 && !t.rgba8) return fail(RR_ERR_INVALID_ARGUMENT, "texture %u has no pixels", i);
+        if (t.width > 32768u || t.height > 32768u) return fail(RR_ERR_UNSUPPORTED, "texture %u is %ux%u", i, t.width, t.height);
+    }
+    for (uint32_t i = 0; i < fs->n_materials; i++)
+        for (int k = 0; k < RR_TEX_COUNT; k++) {
+            int32_t t = fs->materials[i].texture[k];
+            if (t >= (int32_t)fs->n_textures) return fail(RR_ERR_INVALID_ARGUMENT, "material %u texture slot %d = %d out of range", i, k, t);
+        }
+    for (uint32_t i = 0; i < fs->n_meshes; i++) {
+        const rr_mesh& m = fs->meshes[i];
+        if ((m.n_vertices && !m.positions) || (m.n_triangles && !m.indices)) return fail(RR_ERR_INVALID_ARGUMENT, "mesh %u: missing positions/indices", i);
+        if ((m.n_uvs && !m.uvs) || (m.n_uv_faces && !m.uv_indices) || (m.n_normals && !m.normals) || (m.n_normal_faces && !m.normal_indices))
+            return fail(RR_ERR_INVALID_ARGUMENT, "mesh %u: attribute pointer is NULL with a non-zero count", i);
+        if (m.n_triangles >= (1u << 28)) return fail(RR_ERR_UNSUPPORTED, "mesh %u: %u triangles", i, m.n_triangles);
+        for (size_t k = 0; k < (size_t)m.n_triangles * 3; k++)
+            if (m.indices[k] >= m.n_vertices) return fail(RR_ERR_INVALID_ARGUMENT, "mesh %u: vertex index %u out of range", i, m.indices[k]);
+        for (size_t k = 0; k < (size_t)m.n_uv_faces * 3; k++)
+            if (m.uv_indices[k] >= m.n_uvs) return fail(RR_ERR_INVALID_ARGUMENT, "mesh %u: uv index %u out of range", i, m.uv_indices[k]);
+        for (size_t k = 0; k < (size_t)m.n_normal_faces * 3; k++)
+            if (m.normal_indices[k] >= m.n_normals) return fail(RR_ERR_INVALID_ARGUMENT, "mesh %u: normal index %u out of range", i, m.normal_indices[k]);
+        // Mesh::get_normal indexes normals_indices[face] unchecked (reference src/shape/mesh.rs:216): the reference would panic
+        if (m.n_normals > 0 && m.n_normal_faces > 0 && m.n_normal_faces < m.n_triangles)
+            return fail(RR_ERR_INVALID_ARGUMENT, "mesh %u: %u normal faces for %u triangles (the reference panics on this)", i, m.n_normal_faces, m.n_triangles);
+    }
+    for (uint32_t i = 0; i < fs->n_items; i++) {
+        const rr_item& it = fs->items[i];
+        if (it.kind != RR_ITEM_SPHERE && it.kind != RR_ITEM_MESH) return fail(RR_ERR_INVALID_ARGUMENT, "item %u: kind %u", i, it.kind);
+        if (it.material < 0 || it.material >= (int32_t)fs->n_materials || it.material_cache < 0 || it.material_cache >= (int32_t)fs->n_materials)
+            return fail(RR_ERR_INVALID_ARGUMENT, "item %u: material index out of range", i);
+        for (int k = 0; k < RR_TEX_COUNT; k++)
+            if (fs->materials[it.material_cache].texture[k] >= 0)
+                return fail(RR_ERR_INVALID_ARGUMENT, "item %u: material_cache must not carry textures (reference src/shape/mod.rs:769-772)", i);
+        if (it.kind == RR_ITEM_MESH && (it.mesh < 0 || it.mesh >= (int32_t)fs->n_meshes)) return fail(RR_ERR_INVALID_ARGUMENT, "item %u: mesh index %d", i, it.mesh);
+        if (!finite16(it.trans) || !finite16(it.trans_inv)) return fail(RR_ERR_INVALID_ARGUMENT, "item %u: non-finite transform", i);
+    }
+    for (uint32_t i = 0; i < fs->n_lights; i++)
+        if (fs->lights[i].light_type > RR_LIGHT_SPOT) return fail(RR_ERR_INVALID_ARGUMENT, "light %u: type %u", i, fs->lights[i].light_type);
+    return RR_OK;
+}
+
+static void fill_item_matrices(DItem& d, const float* trans, const float* inv) {
+    // rows of the column-major matrices
+    d.inv0 = make_float4(inv[0], inv[4], inv[8], inv[12]);
+    d.inv1 = make_float4(inv[1], inv[5], inv[9], inv[13]);
+    d.inv2 = make_float4(inv[2], inv[6], inv[10], inv[14]);
+    d.inv3 = make_float4(inv[3], inv[7], inv[11], inv[15]);
+    d.tr0 = make_float4(trans[0], trans[4], trans[8], trans[12]);
+    d.tr1 = make_float4(trans[1], trans[5], trans[9], trans[13]);
+    d.tr2 = make_float4(trans[2], trans[6], trans[10], trans[14]);
+}
+
+// world AABB of an item = box of the 8 transformed local-bbox corners
+// (Bounded::aabb, reference src/shape/mod.rs:48-78), computed in double and padded
+static void world_box(const rr_item& it, float* lo, float* hi) {
+    double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+    for (int c = 0; c < 8; c++) {
+        double p[3] = {(c & 1) ? it.bbox_max[0] : it.bbox_min[0], (c & 2) ? it.bbox_max[1] : it.bbox_min[1], (c & 4) ? it.bbox_max[2] : it.bbox_min[2]};
+        for (int r = 0; r < 3; r++) {
+            double v = (double)it.trans[r] * p[0] + (double)it.trans[4 + r] * p[1] + (double)it.trans[8 + r] * p[2] + (double)it.trans[12 + r];
+            l[r] = std::min(l[r], v); h[r] = std::max(h[r], v);
+        }
+    }
+    for (int r = 0; r < 3; r++) {
+        double e = (std::max(std::fabs(l[r]), std::fabs(h[r])) + (h[r] - l[r])) * 1e-5 + 1e-30;
+        lo[r] = (float)(l[r] - e); hi[r] = (float)(h[r] + e);
+        if (!std::isfinite(lo[r])) lo[r] = -3.0e38f;
+        if (!std::isfinite(hi[r])) hi[r] = 3.0e38f;
+    }
+}
+
+static int build_tlas(rr_scene* s, const std::vector<rr_item>& items, std::vector<DNode>* tlas, int32_t* root) {
+    uint32_t n = (uint32_t)items.size();
+    std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
+    for (uint32_t i = 0; i < n; i++) world_box(items[i], &lo[3 * (size_t)i], &hi[3 * (size_t)i]);
+    rr::BvhResult r;
+    if (!rr::build_bvh(lo.data(), hi.data(), n, 1, RR_TLAS_MAX_DEPTH, &r))
+        return fail(RR_ERR_UNSUPPORTED, "scene has too many items (%u) for the top-level depth limit", n);
+    // leaves must name item indices directly: leaf order is a permutation, so re-code each 1-item leaf
+    for (DNode& nd : r.nodes) {
+        int32_t c[2];
+        memcpy(&c[0], &nd.n3.x, 4); memcpy(&c[1], &nd.n3.y, 4);
+        for (int k = 0; k < 2; k++)
+            if (c[k] < 0) { uint32_t first = RR_LEAF_FIRST(~c[k]); c[k] = ~(int32_t)r.order[first]; }
+        memcpy(&nd.n3.x, &c[0], 4); memcpy(&nd.n3.y, &c[1], 4);
+    }
+    *root = r.root;
+    if (r.root < 0) *root = ~(int32_t)r.order[RR_LEAF_FIRST(~r.root)];
+    *tlas = std::move(r.nodes);
+    (void)s;
+    return RR_OK;
+}
+
+extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** out) {
+    if (!out) return fail(RR_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int rc = validate_scene(fs);
+    if (rc != RR_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(RR_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(RR_ERR_INVALID_ARGUMENT, "device %d of %d", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<rr_scene> s(new rr_scene);
+    s->device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+    // u8 -> f32 table, exactly (float)i / 255.0f
+    float lut[256];
+    for (int i = 0; i < 256; i++) lut[i] = (float)i / 255.0f;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_u8_to_f32), lut, sizeof lut));
+
+    // ---- textures: one RGBA8 pool
+    std::vector<DTexture> dtex(fs->n_textures);
+    uint64_t n_texels = 0;
+    for (uint32_t i = 0; i < fs->n_textures; i++) {
+        dtex[i].offset = n_texels; dtex[i].width = fs->textures[i].width; dtex[i].height = fs->textures[i].height;
+        n_texels += (uint64_t)fs->textures[i].width * fs->textures[i].height;
+    }
+    HIP_TRY(s->texels.reserve(std::max<uint64_t>(n_texels, 1) * 4));
+    for (uint32_t i = 0; i < fs->n_textures; i++) {
+        uint64_t n = (uint64_t)dtex[i].width * dtex[i].height;
+        if (n) HIP_TRY(hipMemcpy(s->texels.as<uint32_t>() + dtex[i].offset, fs->textures[i].rgba8, n * 4, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(s->textures.reserve(std::max<size_t>(dtex.size(), 1) * sizeof(DTexture)));
+    if (!dtex.empty()) HIP_TRY(hipMemcpy(s->textures.p, dtex.data(), dtex.size() * sizeof(DTexture), hipMemcpyHostToDevice));
+
+    // ---- materials
+    std::vector<DMaterial> dmat(fs->n_materials);
+    for (uint32_t i = 0; i < fs->n_materials; i++) {
+        const rr_material& m = fs->materials[i];
+        DMaterial& d = dmat[i];
+        memset(&d, 0, sizeof d);
+        for (int k = 0; k < 3; k++) { d.ambient[k] = m.ambient_color[k]; d.base[k] = m.base_color[k]; d.specular[k] = m.specular_color[k]; }
+        d.alpha = m.alpha; d.shininess = m.shininess; d.reflectivity = m.reflectivity; d.refraction_index = m.refraction_index;
+        d.normal_map_strength = m.normal_map_strength; d.shadow_softness = m.shadow_softness; d.roughness = m.roughness;
+        bool any = false;
+        for (int k = 0; k < RR_TEX_COUNT; k++) {
+            d.tex[k] = m.texture[k];
+            if (m.texture[k] >= 0 && fs->textures[m.texture[k]].width > 0) any = true; // has_texture: width > 0
+        }
+        d.flags = (m.texture_filtering_nearest ? RR_MF_NEAREST : 0u) | (m.receive_shadow ? RR_MF_RECEIVE_SHADOW : 0u) |
+                  (m.monte_carlo ? RR_MF_MONTE_CARLO : 0u) | (any ? RR_MF_ANY_TEX : 0u);
+    }
+    HIP_TRY(s->materials.reserve(std::max<size_t>(dmat.size(), 1) * sizeof(DMaterial)));
+    if (!dmat.empty()) HIP_TRY(hipMemcpy(s->materials.p, dmat.data(), dmat.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
+
+    // ---- lights (disabled lights keep their slot: the slot is the RNG stream of their shadow jitter)
+    std::vector<DLight> dl(fs->n_lights);
+    s->n_enabled_lights = 0;
+    for (uint32_t i = 0; i < fs->n_lights; i++) {
+        const rr_light& l = fs->lights[i];
+        for (int k = 0; k < 3; k++) { dl[i].pos[k] = l.pos[k]; dl[i].dir[k] = l.dir[k]; dl[i].color[k] = l.color[k]; }
+        dl[i].intensity = l.intensity; dl[i].max_angle = l.max_angle;
+        dl[i].type = l.light_type | (l.enabled ? 0u : 0x80u);
+        if (l.enabled) s->n_enabled_lights++;
+    }
+    HIP_TRY(s->lights.reserve(std::max<size_t>(dl.size(), 1) * sizeof(DLight)));
+    if (!dl.empty()) HIP_TRY(hipMemcpy(s->lights.p, dl.data(), dl.size() * sizeof(DLight), hipMemcpyHostToDevice));
+
+    // ---- meshes: one BLAS per mesh, shared by every item that names it
+    struct MeshDev { uint32_t node_base, tri_base, n_tris; int32_t root; bool has_normals; };
+    std::vector<MeshDev> md(fs->n_meshes);
+    std::vector<DNode> all_nodes;
+    std::vector<DTri> all_tris;
+    std::vector<DTriAttr> all_attrs;
+    std::vector<uint32_t> all_face_slot;
+    for (uint32_t mi = 0; mi < fs->n_meshes; mi++) {
+        const rr_mesh& m = fs->meshes[mi];
+        uint32_t nt = m.n_triangles;
+        std::vector<float> lo(3 * (size_t)nt), hi(3 * (size_t)nt);
+        for (uint32_t f = 0; f < nt; f++)
+            for (int k = 0; k < 3; k++) {
+                float a = m.positions[3 * (size_t)m.indices[3 * (size_t)f] + k];
+                float b = m.positions[3 * (size_t)m.indices[3 * (size_t)f + 1] + k];
+                float c = m.positions[3 * (size_t)m.indices[3 * (size_t)f + 2] + k];
+                lo[3 * (size_t)f + k] = std::min(a, std::min(b, c));
+                hi[3 * (size_t)f + k] = std::max(a, std::max(b, c));
+            }
+        rr::BvhResult r;
+        if (!rr::build_bvh(lo.data(), hi.data(), nt, RR_MAX_LEAF_TRIS, RR_BLAS_MAX_DEPTH, &r))
+            return fail(RR_ERR_UNSUPPORTED, "mesh %u: BVH depth limit exceeded", mi);
+        md[mi].node_base = (uint32_t)all_nodes.size();
+        md[mi].tri_base = (uint32_t)all_tris.size();
+        md[mi].n_tris = nt;
+        md[mi].root = r.root;
+        md[mi].has_normals = m.n_normals > 0 && m.n_normal_faces > 0;
+        all_nodes.insert(all_nodes.end(), r.nodes.begin(), r.nodes.end());
+        size_t fs_base = all_face_slot.size();
+        all_face_slot.resize(fs_base + nt);
+        for (uint32_t slot = 0; slot < nt; slot++) {
+            uint32_t f = r.order[slot];
+            all_face_slot[fs_base + f] = slot;
+            const uint32_t* ix = m.indices + 3 * (size_t)f;
+            const float *a = m.positions + 3 * (size_t)ix[0], *b = m.positions + 3 * (size_t)ix[1], *c = m.positions + 3 * (size_t)ix[2];
+            DTri t;
+            float fbits; memcpy(&fbits, &f, 4);
+            t.v0 = make_float4(a[0], a[1], a[2], fbits);
+            t.v1 = make_float4(b[0], b[1], b[2], 0.0f);
+            t.v2 = make_float4(c[0], c[1], c[2], 0.0f);
+            all_tris.push_back(t);
+            DTriAttr at;
+            float n[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, uv[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+            if (md[mi].has_normals)
+                for (int v = 0; v < 3; v++)
+                    for (int k = 0; k < 3; k++) n[v][k] = m.normals[3 * (size_t)m.normal_indices[3 * (size_t)f + v] + k];
+            uint32_t flags = 0;
+            if (f < m.n_uv_faces) { // Mesh::get_uv bounds test, reference src/shape/mesh.rs:116
+                flags |= 1u;
+                for (int v = 0; v < 3; v++)
+                    for (int k = 0; k < 2; k++) uv[v][k] = m.uvs[2 * (size_t)m.uv_indices[3 * (size_t)f + v] + k];
+            }
+            float flb; memcpy(&flb, &flags, 4);
+            at.s0 = make_float4(n[0][0], n[0][1], n[0][2], uv[0][0]);
+            at.s1 = make_float4(n[1][0], n[1][1], n[1][2], uv[0][1]);
+            at.s2 = make_float4(n[2][0], n[2][1], n[2][2], uv[1][0]);
+            at.s3 = make_float4(uv[1][1], uv[2][0], uv[2][1], flb);
+            all_attrs.push_back(at);
+        }
+    }
+
+    // ---- items
+    s->h_items.resize(fs->n_items);
+    s->item_mesh.resize(fs->n_items);
+    bool general_w = false;
+    for (uint32_t i = 0; i < fs->n_items; i++) {
+        const rr_item& it = fs->items[i];
+        const rr_material& cache = fs->materials[it.material_cache];
+        const rr_material& full = fs->materials[it.material];
+        DItem& d = s->h_items[i];
+        memset(&d, 0, sizeof d);
+        fill_item_matrices(d, it.trans, it.trans_inv);
+        if (!(it.trans_inv[3] == 0.0f && it.trans_inv[7] == 0.0f && it.trans_inv[11] == 0.0f && it.trans_inv[15] == 1.0f)) general_w = true;
+        for (int k = 0; k < 3; k++) { d.bmin[k] = it.bbox_min[k]; d.bmax[k] = it.bbox_max[k]; }
+        d.radius = it.radius;
+        d.id = it.id;
+        d.material = it.material;
+        uint32_t f = 0;
+        if (it.visible) f |= RR_IF_VISIBLE;
+        if (it.flip_normals) f |= RR_IF_FLIP_NORMALS;
+        if (cache.alpha > 0.0f) f |= RR_IF_CACHE_ALPHA_POS;
+        if (cache.cast_shadow) f |= RR_IF_CACHE_CAST_SHADOW;
+        if (cache.reflection_only) f |= RR_IF_CACHE_REFL_ONLY;
+        if (!(cache.alpha < 1.0f) && cache.backface_cullig) f |= RR_IF_SOLID_BASE; // the cache never has textures
+        if (full.texture[RR_TEX_ALPHA] >= 0 && fs->textures[full.texture[RR_TEX_ALPHA]].width > 0) f |= RR_IF_OCCLUDER_ALPHA_TEX;
+        s->item_mesh[i] = ~0u;
+        if (it.kind == RR_ITEM_SPHERE) {
+            f |= RR_IF_SPHERE;
+        } else {
+            const MeshDev& m = md[it.mesh];
+            s->item_mesh[i] = (uint32_t)it.mesh;
+            d.node_base = m.node_base; d.root = m.root; d.tri_base = m.tri_base; d.n_tris = m.n_tris;
+            if (cache.smooth_shading && m.has_normals) f |= RR_IF_SMOOTH;
+        }
+        d.flags = f;
+    }
+
+    // ---- top level
+    std::vector<DNode> tlas;
+    int32_t tlas_root = 0;
+    uint32_t use_tlas = 0;
+    const char* env_tlas = getenv("RR_TLAS_MIN_ITEMS");
+    uint32_t tlas_min = env_tlas ? (uint32_t)atoi(env_tlas) : 9u;
+    if (fs->n_items >= tlas_min && fs->n_items >= 2) {
+        std::vector<rr_item> items(fs->items, fs->items + fs->n_items);
+        rc = build_tlas(s.get(), items, &tlas, &tlas_root);
+        if (rc != RR_OK) return rc;
+        use_tlas = 1;
+    }
+    uint32_t tlas_base = (uint32_t)all_nodes.size();
+    s->tlas_node_capacity = std::max<uint32_t>((uint32_t)tlas.size(), fs->n_items ? fs->n_items : 1u);
+    all_nodes.insert(all_nodes.end(), tlas.begin(), tlas.end());
+    all_nodes.resize((size_t)tlas_base + s->tlas_node_capacity); // room for rebuilds after transform updates
+
+    auto upload = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = b.reserve(std::max<size_t>(bytes, 16));
+        if (e != hipSuccess) return e;
+        return bytes ? hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    };
+    HIP_TRY(upload(s->nodes, all_nodes.data(), all_nodes.size() * sizeof(DNode)));
+    HIP_TRY(upload(s->tris, all_tris.data(), all_tris.size() * sizeof(DTri)));
+    HIP_TRY(upload(s->attrs, all_attrs.data(), all_attrs.size() * sizeof(DTriAttr)));
+    HIP_TRY(upload(s->face_slot, all_face_slot.data(), all_face_slot.size() * 4));
+    HIP_TRY(upload(s->items, s->h_items.data(), s->h_items.size() * sizeof(DItem)));
+
+    DSceneView& v = s->view;
+    v.items = s->items.as<DItem>(); v.nodes = s->nodes.as<DNode>(); v.tris = s->tris.as<DTri>(); v.attrs = s->attrs.as<DTriAttr>();
+    v.face_slot = s->face_slot.as<uint32_t>();
+    v.materials = s->materials.as<DMaterial>(); v.textures = s->textures.as<DTexture>(); v.texels = s->texels.as<uint32_t>();
+    v.lights = s->lights.as<DLight>();
+    v.n_items = fs->n_items; v.n_lights = fs->n_lights;
+    v.tlas_node_base = tlas_base; v.tlas_root = tlas_root; v.use_tlas = use_tlas; v.general_w = general_w ? 1u : 0u;
+
+    HIP_TRY(s->pool.reserve(POOL_WORDS * 4));
+    HIP_TRY(s->counters.reserve(RR_CNT_WORDS * 8));
+    HIP_TRY(hipEventCreate(&s->frame_a));
+    HIP_TRY(hipEventCreate(&s->frame_b));
+    const char* prof = getenv("RR_PROFILE");
+    s->profiling = prof && atoi(prof) != 0;
+    *out = s.release();
+    return RR_OK;
+}
+
+extern "C" void rr_scene_destroy(rr_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    DevBuf* all[] = {&s->items, &s->nodes, &s->tris, &s->attrs, &s->face_slot, &s->materials, &s->textures, &s->texels, &s->lights,
+                     &s->acc_rgb, &s->acc_normal, &s->acc_depth, &s->acc_id, &s->region_xy, &s->sample_xy, &s->pool, &s->counters};
+    for (DevBuf* b : all) b->release();
+    for (int i = 0; i < 2; i++) for (int k = 0; k < 4; k++) s->q[i][k].release();
+    for (int k = 0; k < 4; k++) { s->sq[k].release(); s->tmp_out[k].release(); }
+    for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
+    for (auto& t : s->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    if (s->frame_a) (void)hipEventDestroy(s->frame_a);
+    if (s->frame_b) (void)hipEventDestroy(s->frame_b);
+    delete s;
+}
+
+extern "C" int rr_scene_update_transforms(rr_scene* s, const float* trans, const float* trans_inv) {
+    if (!s || !trans || !trans_inv) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIP_TRY(hipSetDevice(s->device));
+    uint32_t n = (uint32_t)s->h_items.size();
+    bool general_w = false;
+    std::vector<rr_item> tmp(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const float *t = trans + 16 * (size_t)i, *ti = trans_inv + 16 * (size_t)i;
+        if (!finite16(t) || !finite16(ti)) return fail(RR_ERR_INVALID_ARGUMENT, "item %u: non-finite transform", i);
+        fill_item_matrices(s->h_items[i], t, ti);
+        if (!(ti[3] == 0.0f && ti[7] == 0.0f && ti[11] == 0.0f && ti[15] == 1.0f)) general_w = true;
+        memset(&tmp[i], 0, sizeof(rr_item));
+        memcpy(tmp[i].trans, t, 64);
+        for (int k = 0; k < 3; k++) { tmp[i].bbox_min[k] = s->h_items[i].bmin[k]; tmp[i].bbox_max[k] = s->h_items[i].bmax[k]; }
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(s->items.p, s->h_items.data(), n * sizeof(DItem), hipMemcpyHostToDevice));
+    s->view.general_w = general_w ? 1u : 0u;
+    if (s->view.use_tlas) {
+        std::vector<DNode> tlas; int32_t root = 0;
+        int rc = build_tlas(s, tmp, &tlas, &root);
+        if (rc != RR_OK) return rc;
+        if (tlas.size() > s->tlas_node_capacity) return fail(RR_ERR_DEVICE, "top-level rebuild needs %zu nodes, capacity %u", tlas.size(), s->tlas_node_capacity);
+        if (!tlas.empty()) HIP_TRY(hipMemcpy(s->nodes.as<DNode>() + s->view.tlas_node_base, tlas.data(), tlas.size() * sizeof(DNode), hipMemcpyHostToDevice));
+        s->view.tlas_root = root;
+    }
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// frame
+// ---------------------------------------------------------------------------
+static int check_frame_args(const rr_scene* s, const rr_camera* cam, const rr_config* cfg) {
+    if (!s || !cam || !cfg) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (cfg->samples == 0) return fail(RR_ERR_INVALID_ARGUMENT, "samples must be >= 1");
+    if (cfg->max_recursion > RR_MAX_RECURSION) return fail(RR_ERR_UNSUPPORTED, "max_recursion %u > %u", cfg->max_recursion, RR_MAX_RECURSION);
+    if (cam->width == 0 || cam->height == 0 || cam->width > 65535u || cam->height > 65535u) return fail(RR_ERR_INVALID_ARGUMENT, "bad frame size %ux%u", cam->width, cam->height);
+    if (!finite16(cam->projection_inverse) || !finite16(cam->view_inverse)) return fail(RR_ERR_INVALID_ARGUMENT, "non-finite camera matrix");
+    return RR_OK;
+}
+
+static hipEvent_t take_event(rr_scene* s) {
+    if (!s->event_pool.empty()) { hipEvent_t e = s->event_pool.back(); s->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ScopedTimer {
+    rr_scene* s; hipStream_t st; int kind; hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(rr_scene* s_, hipStream_t st_, int kind_) : s(s_), st(st_), kind(kind_) {
+        if (s->profiling) { a = take_event(s); b = take_event(s); (void)hipEventRecord(a, st); }
+    }
+    ~ScopedTimer() { if (s->profiling) { (void)hipEventRecord(b, st); s->timed.push_back(TimedLaunch{a, b, kind}); } }
+};
+
+static void resolve_timers(rr_scene* s) {
+    for (auto& t : s->timed) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            if (t.kind == 0) { s->stats.ms_trace_closest += ms; s->stats.launches_trace_closest++; }
+            else if (t.kind == 1) { s->stats.ms_trace_shadow += ms; s->stats.launches_trace_shadow++; }
+            else if (t.kind == 2) { s->stats.ms_shade += ms; s->stats.launches_shade++; }
+        }
+        s->event_pool.push_back(t.a); s->event_pool.push_back(t.b);
+    }
+    s->timed.clear();
+}
+
+static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy,
+                                const rr_region* rg, const rr_frame* out, bool frame_layout, hipStream_t st, const volatile int* cancel) {
+    HIP_TRY(hipSetDevice(s->device));
+    const uint32_t W = cam->width, H = cam->height;
+    // ---- region map
+    if (memcmp(&s->region_cached, rg, sizeof *rg) != 0 || s->region_w != W || s->region_h != H) {
+        fill_region(W, H, *rg, &s->h_region_xy);
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(s->region_xy.reserve(std::max<size_t>(s->h_region_xy.size(), 1) * 4));
+        if (!s->h_region_xy.empty()) HIP_TRY(hipMemcpy(s->region_xy.p, s->h_region_xy.data(), s->h_region_xy.size() * 4, hipMemcpyHostToDevice));
+        s->region_cached = *rg; s->region_w = W; s->region_h = H;
+    }
+    const uint32_t npix = (uint32_t)s->h_region_xy.size();
+    memset(&s->stats, 0, sizeof s->stats);
+    if (npix == 0) return RR_OK;
+
+    // ---- frame constants
+    DFrame fr;
+    memset(&fr, 0, sizeof fr);
+    memcpy(fr.proj_inv, cam->projection_inverse, 64);
+    memcpy(fr.view_inv, cam->view_inverse, 64);
+    fr.width = W; fr.height = H; fr.samples = cfg->samples; fr.cell_size = cell_size_of(cfg->samples);
+    fr.max_recursion = cfg->max_recursion; fr.monte_carlo = cfg->monte_carlo ? 1u : 0u; fr.gamma = cfg->gamma_correction ? 1u : 0u;
+    fr.dof = (cfg->aperture_size > 1.0f && cfg->focal_length > 1.0f) ? 1u : 0u;
+    fr.focal_length = cfg->focal_length; fr.aperture_size = cfg->aperture_size; fr.fog_density = cfg->fog_density;
+    for (int k = 0; k < 3; k++) fr.fog_color[k] = cfg->fog_color[k];
+    fr.seed_lo = (uint32_t)cfg->seed; fr.seed_hi = (uint32_t)(cfg->seed >> 32);
+    fr.n_region_pixels = npix;
+
+    // ---- sample table
+    std::vector<uint16_t> table;
+    if (!sample_xy) {
+        table.resize((size_t)cfg->samples * 2);
+        rr_sample_table(cfg->samples, table.data(), nullptr);
+        sample_xy = table.data();
+    }
+    HIP_TRY(s->sample_xy.reserve((size_t)cfg->samples * 4));
+    HIP_TRY(hipMemcpyAsync(s->sample_xy.p, sample_xy, (size_t)cfg->samples * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st)); // `table` is a stack-local staging buffer
+
+    // ---- accumulators
+    HIP_TRY(s->acc_rgb.reserve((size_t)npix * 24));
+    HIP_TRY(s->acc_normal.reserve((size_t)npix * 24));
+    HIP_TRY(s->acc_depth.reserve((size_t)npix * 8));
+    HIP_TRY(s->acc_id.reserve((size_t)npix * 4));
+    HIP_TRY(hipMemsetAsync(s->acc_rgb.p, 0, (size_t)npix * 24, st));
+    HIP_TRY(hipMemsetAsync(s->acc_normal.p, 0, (size_t)npix * 24, st));
+    HIP_TRY(hipMemsetAsync(s->acc_depth.p, 0, (size_t)npix * 8, st));
+    HIP_TRY(hipMemsetAsync(s->acc_id.p, 0, (size_t)npix * 4, st));
+    HIP_TRY(hipMemsetAsync(s->counters.p, 0, RR_CNT_WORDS * 8, st));
+    DAccum acc{s->acc_rgb.as<long long>(), s->acc_normal.as<long long>(), s->acc_depth.as<long long>(), s->acc_id.as<uint32_t>()};
+
+    // ---- batch sizing.  Level d (1-based depth) holds at most B * 2^(d-1) rays, d <= max_recursion + 1;
+    // odd levels live in queue 0, even levels in queue 1.
+    const uint32_t R = cfg->max_recursion;
+    uint64_t f_odd = 1, f_even = 0;
+    for (uint32_t d = 1; d <= R + 1; d++) { uint64_t f = 1ull << (d - 1); if (d & 1) f_odd = std::max(f_odd, f); else f_even = std::max(f_even, f); }
+    const char* env_budget = getenv("RR_QUEUE_BUDGET_MB");
+    uint64_t budget = (env_budget ? (uint64_t)atoll(env_budget) : 16384ull) << 20;
+    const uint64_t total_primary = (uint64_t)npix * cfg->samples;
+    uint64_t B = budget / (56ull * (f_odd + f_even));
+    B = std::max<uint64_t>(B, 4096);
+    B = std::min<uint64_t>(B, total_primary);
+    B = std::min<uint64_t>(B, 0x7fffffffull / std::max<uint64_t>(f_odd, 1));
+    if (B > npix) B = (B / npix) * npix; // whole sample slices when possible
+    const uint64_t cap[2] = {B * f_odd, std::max<uint64_t>(B * f_even, 1)};
+    const size_t elem[4] = {16, 16, 8, 16};
+    for (int i = 0; i < 2; i++)
+        if (cap[i] > s->q_cap[i]) {
+            for (int k = 0; k < 4; k++) HIP_TRY(s->q[i][k].reserve(cap[i] * elem[k]));
+            s->q_cap[i] = cap[i];
+        }
+    const char* env_chunk = getenv("RR_SHADE_CHUNK");
+    const uint64_t chunk = env_chunk ? std::max<uint64_t>(65536, (uint64_t)atoll(env_chunk)) : (4ull << 20);
+    const uint64_t sq_need = std::max<uint64_t>(1, std::min<uint64_t>(chunk, cap[0]) * std::max<uint32_t>(s->n_enabled_lights, 1u));
+    if (sq_need > s->sq_cap) {
+        for (int k = 0; k < 4; k++) HIP_TRY(s->sq[k].reserve(sq_need * 16));
+        s->sq_cap = sq_need;
+    }
+    DRayQueue Q[2];
+    for (int i = 0; i < 2; i++) { Q[i].r0 = s->q[i][0].as<float4>(); Q[i].r1 = s->q[i][1].as<float4>(); Q[i].r2 = s->q[i][2].as<uint2>(); Q[i].hit = s->q[i][3].as<uint4>(); }
+    DShadowQueue SQ{s->sq[0].as<float4>(), s->sq[1].as<float4>(), s->sq[2].as<float4>(), s->sq[3].as<uint4>()};
+
+    uint32_t* pool = s->pool.as<uint32_t>();
+    unsigned long long* counters = s->counters.as<unsigned long long>();
+    const int trace_grid = s->n_cus * 4;   // 40 KB of LDS stack per workgroup -> 4 workgroups per CU
+    const int shade_grid_max = s->n_cus * 8;
+
+    HIP_TRY(hipEventRecord(s->frame_a, st));
+    for (uint64_t first = 0; first < total_primary; first += B) {
+        if (cancel && *cancel) { (void)hipStreamSynchronize(st); return fail(RR_ERR_CANCELLED, "cancelled"); }
+        const uint32_t n_batch = (uint32_t)std::min<uint64_t>(B, total_primary - first);
+        uint32_t next_word = 0;
+        auto word = [&]() -> uint32_t* { return pool + (next_word++); };
+        HIP_TRY(hipMemsetAsync(pool, 0, POOL_WORDS * 4, st));
+        // level counts live in the first words of the pool
+        uint32_t* level_count = pool; next_word = R + 4;
+        // The batch covers primary indices [first, first + n_batch): index i -> sample i / npix, pixel i % npix.
+        hipLaunchKernelGGL(k_raygen, dim3((n_batch + RR_BLOCK - 1) / RR_BLOCK), dim3(RR_BLOCK), 0, st, fr, s->region_xy.as<uint32_t>(),
+                           s->sample_xy.as<uint16_t>(), (unsigned long long)first, n_batch, Q[0], &level_count[1], counters);
+        uint64_t ub = n_batch; // upper bound of the level size
+        for (uint32_t d = 1; d <= R + 1; d++) {
+            const DRayQueue& qin = Q[(d - 1) & 1];
+            const DRayQueue& qout = Q[d & 1];
+            {
+                ScopedTimer t(s, st, 0);
+                hipLaunchKernelGGL(k_trace_closest, dim3(trace_grid), dim3(RR_BLOCK), 0, st, s->view, qin, &level_count[d], word());
+            }
+            for (uint64_t c0 = 0; c0 < ub; c0 += chunk) {
+                const uint64_t c1 = std::min<uint64_t>(c0 + chunk, ub);
+                if (next_word + 3 >= POOL_WORDS) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise RR_SHADE_CHUNK");
+                uint32_t* sq_count = word();
+                const int grid = (int)std::min<uint64_t>((c1 - c0 + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)shade_grid_max);
+                {
+                    ScopedTimer t(s, st, 2);
+                    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, fr, s->region_xy.as<uint32_t>(), qin, &level_count[d],
+                                       (uint32_t)c0, (uint32_t)c1, qout, &level_count[d + 1], SQ, sq_count, acc, counters);
+                }
+                if (s->n_enabled_lights) {
+                    ScopedTimer t(s, st, 1);
+                    hipLaunchKernelGGL(k_trace_shadow, dim3(trace_grid), dim3(RR_BLOCK), 0, st, s->view, SQ, sq_count, word(), acc);
+                }
+            }
+            ub = std::min<uint64_t>(ub * 2, cap[d & 1]);
+        }
+        HIP_TRY(hipGetLastError());
+        // batches are stream-ordered; only a caller that can cancel needs the host to keep pace with the device
+        if (cancel && first + B < total_primary) HIP_TRY(hipStreamSynchronize(st));
+    }
+    hipLaunchKernelGGL(k_resolve, dim3((npix + RR_BLOCK - 1) / RR_BLOCK), dim3(RR_BLOCK), 0, st, fr, s->region_xy.as<uint32_t>(), acc,
+                       out->rgba8, out->normal, out->depth, out->object_id, frame_layout ? 1u : 0u);
+    HIP_TRY(hipEventRecord(s->frame_b, st));
+    HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
+extern "C" int rr_render_region_device(rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy,
+                                       const rr_region* rg, const rr_frame* out, void* hip_stream, const volatile int* cancel) {
+    int rc = check_frame_args(s, cam, cfg);
+    if (rc != RR_OK) return rc;
+    rc = check_region(cam->width, cam->height, rg);
+    if (rc != RR_OK) return rc;
+    if (!out || !out->rgba8) return fail(RR_ERR_INVALID_ARGUMENT, "out->rgba8 is required");
+    std::lock_guard<std::mutex> lk(s->mu);
+    return render_region_locked(s, cam, cfg, sample_xy, rg, out, false, (hipStream_t)hip_stream, cancel);
+}
+
+extern "C" int rr_render(rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy, const rr_frame* out,
+                         const volatile int* cancel) {
+    int rc = check_frame_args(s, cam, cfg);
+    if (rc != RR_OK) return rc;
+    if (!out || !out->rgba8) return fail(RR_ERR_INVALID_ARGUMENT, "out->rgba8 is required");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t np = (size_t)cam->width * cam->height;
+    const size_t bytes[4] = {np * 4, np * 12, np * 4, np * 4};
+    void* host[4] = {out->rgba8, out->normal, out->depth, out->object_id};
+    rr_frame dev{};
+    void** devp[4] = {(void**)&dev.rgba8, (void**)&dev.normal, (void**)&dev.depth, (void**)&dev.object_id};
+    for (int k = 0; k < 4; k++)
+        if (host[k]) { HIP_TRY(s->tmp_out[k].reserve(bytes[k])); *devp[k] = s->tmp_out[k].p; }
+    rr_region whole{8, 8, 1, 0}; // 8x8 tiles: one wave = one tile of primary rays
+    rc = render_region_locked(s, cam, cfg, sample_xy, &whole, &dev, true, nullptr, cancel);
+    if (rc != RR_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    for (int k = 0; k < 4; k++)
+        if (host[k]) HIP_TRY(hipMemcpy(host[k], s->tmp_out[k].p, bytes[k], hipMemcpyDeviceToHost));
+    return RR_OK;
+}
+
+extern "C" int rr_scene_last_stats(const rr_scene* cs, rr_frame_stats* out) {
+    if (!cs || !out) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
+    rr_scene* s = const_cast<rr_scene*>(cs);
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIP_TRY(hipSetDevice(s->device));
+    float ms = 0.0f;
+    if (hipEventSynchronize(s->frame_b) == hipSuccess && hipEventElapsedTime(&ms, s->frame_a, s->frame_b) == hipSuccess) s->stats.ms_total = ms;
+    resolve_timers(s);
+    unsigned long long c[RR_CNT_WORDS];
+    HIP_TRY(hipMemcpy(c, s->counters.p, sizeof c, hipMemcpyDeviceToHost));
+    s->stats.primary_rays = c[RR_CNT_PRIMARY]; s->stats.secondary_rays = c[RR_CNT_SECONDARY];
+    s->stats.shadow_rays = c[RR_CNT_SHADOW]; s->stats.shaded_hits = c[RR_CNT_SHADED];
+    *out = s->stats;
+    return RR_OK;
+}
+
+// profiling switch (per-launch HIP events around the trace / shade kernels)
+extern "C" int rr_scene_set_profiling(rr_scene* s, int enabled) {
+    if (!s) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->profiling = enabled != 0;
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// multi-GPU epilogue: compact per-rank buffers (concatenated in rank order) -> frame order
+// ---------------------------------------------------------------------------
+struct GatherMap { DevBuf index; uint32_t w, h, tw, th, n; int device; };
+static std::mutex g_gather_mu;
+static std::vector<GatherMap*> g_gather_maps;
+
+extern "C" int rr_deinterleave_device(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t n_ranks,
+                                      uint32_t elem_bytes, const void* src, void* dst, int device, void* hip_stream) {
+    rr_region probe{tile_w, tile_h, n_ranks, 0};
+    int rc = check_region(width, height, &probe);
+    if (rc != RR_OK) return rc;
+    if (!src || !dst || elem_bytes == 0 || (elem_bytes & 3u)) return fail(RR_ERR_INVALID_ARGUMENT, "bad buffers or elem_bytes %u", elem_bytes);
+    HIP_TRY(hipSetDevice(device));
+    std::lock_guard<std::mutex> lk(g_gather_mu);
+    GatherMap* gm = nullptr;
+    for (GatherMap* m : g_gather_maps)
+        if (m->w == width && m->h == height && m->tw == tile_w && m->th == tile_h && m->n == n_ranks && m->device == device) gm = m;
+    const uint32_t np = width * height;
+    if (!gm) {
+        std::vector<uint32_t> index(np), xy;
+        uint32_t base = 0;
+        for (uint32_t r = 0; r < n_ranks; r++) {
+            rr_region rg{tile_w, tile_h, n_ranks, r};
+            fill_region(width, height, rg, &xy);
+            for (uint32_t p = 0; p < xy.size(); p++) index[(size_t)(xy[p] >> 16) * width + (xy[p] & 0xffffu)] = base + p;
+            base += (uint32_t)xy.size();
+        }
+        gm = new GatherMap{DevBuf(), width, height, tile_w, tile_h, n_ranks, device};
+        HIP_TRY(gm->index.reserve((size_t)np * 4));
+        HIP_TRY(hipMemcpy(gm->index.p, index.data(), (size_t)np * 4, hipMemcpyHostToDevice));
+        g_gather_maps.push_back(gm);
+    }
+    const uint32_t words = elem_bytes / 4;
+    const uint64_t total = (uint64_t)np * words;
+    hipLaunchKernelGGL(k_gather_frame, dim3((uint32_t)((total + RR_BLOCK - 1) / RR_BLOCK)), dim3(RR_BLOCK), 0, (hipStream_t)hip_stream,
+                       gm->index.as<uint32_t>(), np, words, (const uint32_t*)src, (uint32_t*)dst);
+    HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// pick (reference src/raytracing.rs:237-273): pixel-centre ray, one closest-hit query
+// ---------------------------------------------------------------------------
+extern "C" int rr_pick(rr_scene* s, const rr_camera* cam, int x, int y, rr_pick_result* out) {
+    if (!s || !cam || !out) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (x < 0 || y < 0 || (uint32_t)x >= cam->width || (uint32_t)y >= cam->height) return fail(RR_ERR_INVALID_ARGUMENT, "pixel (%d,%d) outside %ux%u", x, y, cam->width, cam->height);
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIP_TRY(hipSetDevice(s->device));
+    DFrame fr;
+    memset(&fr, 0, sizeof fr);
+    memcpy(fr.proj_inv, cam->projection_inverse, 64);
+    memcpy(fr.view_inv, cam->view_inverse, 64);
+    fr.width = cam->width; fr.height = cam->height; fr.samples = 1; fr.cell_size = 1; fr.n_region_pixels = 1;
+    DevBuf scratch;
+    HIP_TRY(scratch.reserve(256));
+    // layout: [0] region_xy, [4] sample_xy (2 x u16), [16] r0, [32] r1, [48] r2, [64] hit, [96] count, [100] head, [128] counters
+    char* b = scratch.as<char>();
+    uint32_t h_xy = (uint32_t)x | ((uint32_t)y << 16);
+    HIP_TRY(hipMemset(b, 0, 256));
+    HIP_TRY(hipMemcpy(b, &h_xy, 4, hipMemcpyHostToDevice));
+    DRayQueue q{(float4*)(b + 16), (float4*)(b + 32), (uint2*)(b + 48), (uint4*)(b + 64)};
+    hipLaunchKernelGGL(k_raygen, dim3(1), dim3(RR_BLOCK), 0, nullptr, fr, (const uint32_t*)b, (const uint16_t*)(b + 4), 0ull, 1u, q,
+                       (uint32_t*)(b + 96), (unsigned long long*)(b + 128));
+    hipLaunchKernelGGL(k_trace_closest, dim3(1), dim3(RR_BLOCK), 0, nullptr, s->view, q, (const uint32_t*)(b + 96), (uint32_t*)(b + 100));
+    uint32_t hit[4];
+    HIP_TRY(hipMemcpy(hit, b + 64, 16, hipMemcpyDeviceToHost));
+    scratch.release();
+    memset(out, 0, sizeof *out);
+    if ((int32_t)hit[1] >= 0) {
+        out->hit = 1; out->item_index = hit[1]; out->object_id = s->h_items[hit[1]].id;
+        memcpy(&out->distance, &hit[0], 4);
+    }
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device arithmetic probe (tests/test_device_math.py): runs rr_math.h functions on the GPU
+// ---------------------------------------------------------------------------
+extern "C" int rr_math_probe(int op, const float* a, const float* b, const float* c, int n, float* out0, float* out1, float* out2,
+                             uint64_t seed, int device) {
+    if (n <= 0 || !a || !out0) return fail(RR_ERR_INVALID_ARGUMENT, "bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    DevBuf in[3], o[3];
+    const float* src[3] = {a, b, c};
+    float* dst[3] = {out0, out1, out2};
+    for (int k = 0; k < 3; k++) {
+        HIP_TRY(in[k].reserve((size_t)n * 4)); HIP_TRY(o[k].reserve((size_t)n * 4));
+        if (src[k]) HIP_TRY(hipMemcpy(in[k].p, src[k], (size_t)n * 4, hipMemcpyHostToDevice));
+        else HIP_TRY(hipMemset(in[k].p, 0, (size_t)n * 4));
+        HIP_TRY(hipMemset(o[k].p, 0, (size_t)n * 4));
+    }
+    hipLaunchKernelGGL(k_math_probe, dim3((n + 255) / 256), dim3(256), 0, nullptr, op, in[0].as<float>(), in[1].as<float>(), in[2].as<float>(), n,
+                       o[0].as<float>(), o[1].as<float>(), o[2].as<float>(), (uint32_t)seed, (uint32_t)(seed >> 32));
+    HIP_TRY(hipDeviceSynchronize());
+    for (int k = 0; k < 3; k++) {
+        if (dst[k]) HIP_TRY(hipMemcpy(dst[k], o[k].p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        in[k].release(); o[k].release();
+    }
+    return RR_OK;
+}

@@ -1,0 +1,19 @@
+// rr_bvh.h — host BVH2 builder (see rr_bvh.cpp).
+#pragma once
+#include <stdint.h>
+#include <vector>
+#include "rr_device.h"
+
+namespace rr {
+
+struct BvhResult {
+    std::vector<DNode> nodes;    // child indices relative to nodes[0]
+    std::vector<uint32_t> order; // primitive ids in leaf order
+    int32_t root;                // node index, or a leaf code when the whole set is one leaf
+    int depth;                   // inner levels on the longest root-to-leaf path
+};
+
+// boxes_lo / boxes_hi: n * 3 floats.  Returns false if the depth limit could not be met.
+bool build_bvh(const float* boxes_lo, const float* boxes_hi, uint32_t n, uint32_t max_leaf, int max_depth, BvhResult* out);
+
+} // namespace rr

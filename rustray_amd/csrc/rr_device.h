@@ -1,0 +1,156 @@
+// rr_device.h — HBM-resident data layout of a scene and of the ray queues.
+// Shared by the host uploader (rr_api.cpp / rr_bvh.cpp) and the kernels.
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+// ---- acceleration structures -------------------------------------------------------------
+// BVH2 node, 64 B, one cache line per visit.  Both children's boxes live in the
+// parent, so a traversal step is one 4 x dwordx4 fetch.
+//   n0 = (c0.lo.x, c0.hi.x, c0.lo.y, c0.hi.y)
+//   n1 = (c1.lo.x, c1.hi.x, c1.lo.y, c1.hi.y)
+//   n2 = (c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z)
+//   n3 = (child0, child1, 0, 0)   as int bits
+// child >= 0: inner node index (relative to the structure's node base)
+// child <  0: leaf, ~child = first | (count-1) << 28  (first relative to the prim base)
+struct DNode { float4 n0, n1, n2, n3; };
+
+#define RR_LEAF_FIRST(code) ((uint32_t)(code) & 0x0fffffffu)
+#define RR_LEAF_COUNT(code) ((((uint32_t)(code)) >> 28) + 1u)
+#define RR_MAX_LEAF_TRIS 4
+#define RR_BLAS_MAX_DEPTH 26
+#define RR_TLAS_MAX_DEPTH 12
+#define RR_STACK_DEPTH (RR_BLAS_MAX_DEPTH + RR_TLAS_MAX_DEPTH + 2)
+
+// Triangle for intersection, 48 B (3 x dwordx4), in BVH leaf order:
+//   v0 = (a.xyz, bits(original face index)), v1 = (b.xyz, 0), v2 = (c.xyz, 0)
+struct DTri { float4 v0, v1, v2; };
+
+// Per-triangle shading attributes, 64 B, same order as DTri (fetched once per shaded hit):
+//   s0 = (n0.xyz, uv0.x) s1 = (n1.xyz, uv0.y) s2 = (n2.xyz, uv1.x) s3 = (uv1.y, uv2.x, uv2.y, bits(flags))
+// flags bit0: the reference's get_uv finds uv indices for this face (src/shape/mesh.rs:116)
+struct DTriAttr { float4 s0, s1, s2, s3; };
+
+// ---- items ------------------------------------------------------------------------------
+enum : uint32_t {
+    RR_IF_VISIBLE = 1u << 0,        // ShapeBasics::visible
+    RR_IF_FLIP_NORMALS = 1u << 1,   // ShapeBasics::flip_normals
+    RR_IF_CACHE_ALPHA_POS = 1u << 2,   // material_cache.alpha > 0
+    RR_IF_CACHE_CAST_SHADOW = 1u << 3, // material_cache.cast_shadow
+    RR_IF_CACHE_REFL_ONLY = 1u << 4,   // material_cache.reflection_only
+    RR_IF_SOLID_BASE = 1u << 5,     // !(cache.alpha < 1 || cache has alpha tex) && cache.backface_cullig
+    RR_IF_SMOOTH = 1u << 6,         // cache.smooth_shading && mesh has normals and normal indices
+    RR_IF_SPHERE = 1u << 7,
+    RR_IF_OCCLUDER_ALPHA_TEX = 1u << 8, // full material has an alpha texture (shadow attenuation lookup)
+    RR_IF_HAS_UV_FACES = 1u << 9,
+};
+
+// 208 B instance record.  Rows of the column-major matrices, so that
+// row4(inv0, x, y, z, w) is exactly nalgebra's (M * v).x.
+struct DItem {
+    float4 inv0, inv1, inv2, inv3; // trans_inv rows (inv3 = w row)
+    float4 tr0, tr1, tr2;          // trans rows 0..2 (normals: trans * (n, 0))
+    float bmin[3]; float radius;
+    float bmax[3]; uint32_t flags;
+    uint32_t id;         // ShapeBasics::id
+    int32_t material;    // index into DMaterial[]
+    uint32_t node_base;  // BLAS nodes start (global node index)
+    int32_t root;        // BLAS root: node index relative to node_base, or leaf code
+    uint32_t tri_base;   // first DTri / DTriAttr of the mesh
+    uint32_t n_tris;
+    uint32_t _pad[2];
+};
+
+// 96 B material record
+struct DMaterial {
+    float ambient[3]; float alpha;
+    float base[3]; float shininess;
+    float specular[3]; float reflectivity;
+    float refraction_index, normal_map_strength, shadow_softness, roughness;
+    int32_t tex[8];
+    uint32_t flags; // bit0 nearest filtering, bit1 receive_shadow, bit2 monte_carlo, bit3 any texture
+    uint32_t _pad[3];
+};
+enum : uint32_t { RR_MF_NEAREST = 1u, RR_MF_RECEIVE_SHADOW = 2u, RR_MF_MONTE_CARLO = 4u, RR_MF_ANY_TEX = 8u };
+
+struct DTexture { uint64_t offset; uint32_t width, height; }; // offset in texels into the RGBA8 pool
+
+struct DLight {
+    float pos[3]; float intensity;
+    float dir[3]; float max_angle;
+    float color[3]; uint32_t type; // RR_LIGHT_*; disabled lights are kept (index = RNG stream) with type | 0x80
+};
+
+struct DSceneView {
+    const DItem* items;
+    const DNode* nodes;     // all BLAS nodes, then the TLAS nodes
+    const DTri* tris;
+    const DTriAttr* attrs;
+    const uint32_t* face_slot; // per mesh triangle: original face index -> leaf-order slot
+    const DMaterial* materials;
+    const DTexture* textures;
+    const uint32_t* texels; // RGBA8 pool
+    const DLight* lights;
+    uint32_t n_items;
+    uint32_t n_lights;
+    uint32_t tlas_node_base; // global node index of the TLAS root's array
+    int32_t tlas_root;       // node index relative to tlas_node_base, leaf code, or 0 with use_tlas = 0
+    uint32_t use_tlas;
+    uint32_t general_w;      // some trans_inv has a w row other than (0,0,0,1)
+};
+
+// ---- per-frame constants ----------------------------------------------------------------
+struct DFrame {
+    float proj_inv[16];
+    float view_inv[16];
+    uint32_t width, height;
+    uint32_t samples, cell_size;
+    uint32_t max_recursion;
+    uint32_t monte_carlo, gamma, dof;
+    float focal_length, aperture_size, fog_density;
+    float fog_color[3];
+    uint32_t seed_lo, seed_hi;
+    uint32_t n_region_pixels;
+    uint32_t _pad;
+};
+
+// ---- ray queues (SoA of 16-byte groups, 56 B per ray) -------------------------------------
+//   r0 = (origin.xyz, throughput)
+//   r1 = (dir.xyz (normalised), bits(region pixel index))
+//   r2 = (sample | depth << 16 | idcarrier << 24, path node index)
+//   hit = (bits(toi), item index or -1, face id (+ n_tris for back faces), 0)
+struct DRayQueue {
+    float4* r0;
+    float4* r1;
+    uint2* r2;
+    uint4* hit;
+};
+
+// shadow-ray queue, 64 B per ray
+//   s0 = (origin.xyz, limit)      limit = distance to the light, or +FLT_MAX for directional lights
+//   s1 = (dir.xyz, receiver material alpha)
+//   s2 = (contribution rgb, bits(region pixel index))
+//   s3 = (receiver item, depth, 0, 0)
+struct DShadowQueue {
+    float4* s0;
+    float4* s1;
+    float4* s2;
+    uint4* s3;
+};
+
+// fixed-point accumulators: colour and normal scaled by 2^24, depth by 2^16
+#define RR_FIX_SCALE 16777216.0f
+#define RR_FIX_CLAMP 32768.0f
+#define RR_DEPTH_SCALE 65536.0f
+struct DAccum {
+    long long* rgb;    // n_region_pixels * 3
+    long long* normal; // n_region_pixels * 3
+    long long* depth;  // n_region_pixels
+    uint32_t* object_id; // n_region_pixels
+};
+
+// device-side counters (one block of 64-bit words)
+enum {
+    RR_CNT_PRIMARY = 0, RR_CNT_SECONDARY, RR_CNT_SHADOW, RR_CNT_SHADED,
+    RR_CNT_WORDS = 8
+};

@@ -1,0 +1,1010 @@
+// rr_kernels.hip — the trace loop of rustray as a wavefront path tracer for gfx950.
+//
+// Replaces, for a whole frame, Raytracing::render / trace /
+// get_color_depth_normal_id (reference src/raytracing.rs:275-998) and the
+// Shape implementations under it (src/shape/mesh.rs, src/shape/sphere.rs,
+// src/shape/mod.rs:510-629, :755-761).
+//
+// The reference recursion (every hit may spawn a reflection AND a refraction
+// child, src/raytracing.rs:938-971) is flattened breadth-first: all path nodes
+// of one recursion depth form a ray queue in HBM, and one depth level is
+//     trace_closest  ->  shade  ->  trace_shadow
+// `shade` appends the next level's rays (wave ballot + prefix compaction, one
+// atomic per wave) and the shadow rays of its lights.  A node's colour is an
+// affine function of its children (c = A + wR*R + wT*T with scalar weights), so
+// each ray carries one scalar throughput and every node adds throughput * A into
+// per-pixel fixed-point accumulators: integer adds commute, hence the frame is
+// bit-identical for any scheduling, batching, tiling or GPU count.
+//
+// Kernels are persistent: a fixed grid of 256-thread workgroups pulls 64-ray
+// packets from the queue with one atomic per wave, so a launch never depends on
+// the (device-resident) queue length and the host never synchronises inside a
+// batch.
+#include "rr_device.h"
+#include "rr_math.h"
+
+#define RR_BLOCK 256
+#define RR_WAVE 64
+
+__constant__ float c_u8_to_f32[256]; // i / 255.0f, exactly as `(p[0] as f32) / 255.0`
+
+// ---------------------------------------------------------------------------
+// geometry primitives: parry3d 0.13 restated (ray_aabb.rs, ray_triangle.rs, ray_ball.rs)
+// ---------------------------------------------------------------------------
+struct LRay { f3 o, d; };
+
+// ShapeBasics::get_inverse_ray, reference src/shape/mod.rs:755-761
+RR_DEV LRay inverse_ray(const DItem& it, f3 o, f3 d, bool general_w) {
+    LRay r;
+    float ox = row4(it.inv0, o.x, o.y, o.z, 1.0f);
+    float oy = row4(it.inv1, o.x, o.y, o.z, 1.0f);
+    float oz = row4(it.inv2, o.x, o.y, o.z, 1.0f);
+    if (general_w) { // Point3::from_homogeneous divides by w; w == 1 exactly for affine inverses
+        float w = row4(it.inv3, o.x, o.y, o.z, 1.0f);
+        ox = ox / w; oy = oy / w; oz = oz / w;
+    }
+    r.o = mk3(ox, oy, oz);
+    r.d = mk3(row4(it.inv0, d.x, d.y, d.z, 0.0f), row4(it.inv1, d.x, d.y, d.z, 0.0f), row4(it.inv2, d.x, d.y, d.z, 0.0f));
+    return r;
+}
+RR_DEV f3 to_local_point(const DItem& it, f3 p, bool general_w) {
+    float x = row4(it.inv0, p.x, p.y, p.z, 1.0f);
+    float y = row4(it.inv1, p.x, p.y, p.z, 1.0f);
+    float z = row4(it.inv2, p.x, p.y, p.z, 1.0f);
+    if (general_w) { float w = row4(it.inv3, p.x, p.y, p.z, 1.0f); x = x / w; y = y / w; z = z / w; }
+    return mk3(x, y, z);
+}
+RR_DEV f3 to_world_normal(const DItem& it, f3 n) {
+    return normalize3(mk3(row4(it.tr0, n.x, n.y, n.z, 0.0f), row4(it.tr1, n.x, n.y, n.z, 0.0f), row4(it.tr2, n.x, n.y, n.z, 0.0f)));
+}
+
+// Aabb::cast_local_ray(ray, f32::MAX, solid)
+RR_DEV bool aabb_cast(const float* mins, const float* maxs, const LRay& ray, bool solid, float* toi) {
+    float tmin = 0.0f, tmax = RR_FLT_MAX;
+    const float o[3] = {ray.o.x, ray.o.y, ray.o.z};
+    const float d[3] = {ray.d.x, ray.d.y, ray.d.z};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (d[i] == 0.0f) {
+            if (o[i] < mins[i] || o[i] > maxs[i]) return false;
+        } else {
+            float denom = 1.0f / d[i];
+            float a = (mins[i] - o[i]) * denom;
+            float b = (maxs[i] - o[i]) * denom;
+            float inear = (a > b) ? b : a;
+            float ifar = (a > b) ? a : b;
+            tmin = rs_max(tmin, inear);
+            tmax = rs_min(tmax, ifar);
+            if (tmin > tmax) return false;
+        }
+    }
+    *toi = (tmin == 0.0f && !solid) ? tmax : tmin;
+    return true;
+}
+
+// local_ray_intersection_with_triangle: toi and side only (the normal is rebuilt when shading)
+// `back` is parry's FeatureId side (d >= 0); `neg` says the returned normal is -normalize(n) (t < 0).
+// They differ only when the origin lies exactly in the triangle's plane.
+RR_DEV bool ray_triangle(f3 a, f3 b, f3 c, const LRay& ray, float* toi_out, uint32_t* side_out) {
+    f3 ab = b - a, ac = c - a;
+    f3 n = cross3(ab, ac);
+    float d = dot3(n, ray.d);
+    if (d == 0.0f) return false;
+    f3 ap = ray.o - a;
+    float t = dot3(ap, n);
+    if ((t < 0.0f && d < 0.0f) || (t > 0.0f && d > 0.0f)) return false;
+    bool back = !(d < 0.0f);
+    d = rr_abs(d);
+    f3 e = -cross3(ray.d, ap);
+    float v, w, toi;
+    if (t < 0.0f) {
+        v = -dot3(ac, e);
+        if (v < 0.0f || v > d) return false;
+        w = dot3(ab, e);
+        if (w < 0.0f || v + w > d) return false;
+        float invd = 1.0f / d;
+        toi = -t * invd;
+    } else {
+        v = dot3(ac, e);
+        if (v < 0.0f || v > d) return false;
+        w = -dot3(ab, e);
+        if (w < 0.0f || v + w > d) return false;
+        float invd = 1.0f / d;
+        toi = t * invd;
+    }
+    if (!(toi <= RR_FLT_MAX)) return false;
+    *toi_out = toi;
+    *side_out = (back ? 2u : 0u) | ((t < 0.0f) ? 1u : 0u);
+    return true;
+}
+
+// ray_toi_with_ball + Ball::cast_local_ray_and_get_normal (centre = local origin)
+RR_DEV bool ray_ball(float radius, const LRay& ray, bool solid, float* toi_out, bool* inside_out) {
+    float a = dot3(ray.d, ray.d);
+    float b = dot3(ray.o, ray.d);
+    float c = dot3(ray.o, ray.o) - radius * radius;
+    bool inside; float toi;
+    if (a == 0.0f) {
+        if (c > 0.0f) return false;
+        inside = true; toi = 0.0f;
+    } else if (c > 0.0f && b > 0.0f) {
+        return false;
+    } else {
+        float delta = b * b - a * c;
+        if (delta < 0.0f) return false;
+        float sq = sqrtf(delta);
+        float t = (-b - sq) / a;
+        if (t <= 0.0f) { inside = true; toi = solid ? 0.0f : (-b + sq) / a; }
+        else { inside = false; toi = t; }
+    }
+    if (toi > RR_FLT_MAX) return false;
+    *toi_out = toi; *inside_out = inside;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// BVH2 traversal.  Per-lane stack in LDS, lane-interleaved (conflict free).
+// ---------------------------------------------------------------------------
+#define STK(sp) s_stack[(sp) * RR_BLOCK + threadIdx.x]
+
+struct SlabRay { f3 o, inv; };
+
+// Conservative slab test against a (builder-padded) box.  The relative slack
+// on both ends widens the box in proportion to its distance from the origin,
+// which is also how the rounding slop of the exact triangle test grows.
+RR_DEV bool slab2(float lox, float hix, float loy, float hiy, float loz, float hiz,
+                  const SlabRay& r, float bound, float* entry) {
+    float ax = (lox - r.o.x) * r.inv.x, bx = (hix - r.o.x) * r.inv.x;
+    float ay = (loy - r.o.y) * r.inv.y, by = (hiy - r.o.y) * r.inv.y;
+    float az = (loz - r.o.z) * r.inv.z, bz = (hiz - r.o.z) * r.inv.z;
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), RR_FLT_MAX));
+    float tn_c = tn * 0.999998f;
+    *entry = tn;
+    return tn_c <= tf * 1.000002f && tn_c <= bound;
+}
+
+// Nearest triangle of one mesh (TriMesh::cast_local_ray_and_get_normal,
+// reference src/shape/mesh.rs:67).  Ties at bit-equal toi go to the lowest
+// ORIGINAL face index.  `gbound`: hits beyond it cannot win upstream.
+// Returns slot (leaf-order triangle index) and side.
+struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool found; };
+
+RR_DEV void blas_closest(const DSceneView& sc, const DItem& it, const LRay& ray, float gbound,
+                         int* s_stack, int sp_base, TriBest* out) {
+    TriBest best; best.found = false; best.t = RR_FLT_MAX; best.slot = 0; best.face = 0xffffffffu; best.side = 0u;
+    SlabRay sr; sr.o = ray.o; sr.inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    const DNode* nodes = sc.nodes + it.node_base;
+    const DTri* tris = sc.tris + it.tri_base;
+    int sp = sp_base;
+    int cur = it.root;
+    for (;;) {
+        if (cur >= 0) {
+            const DNode nd = nodes[cur];
+            float bound = fminf(gbound, best.t);
+            float e0, e1;
+            bool h0 = slab2(nd.n0.x, nd.n0.y, nd.n0.z, nd.n0.w, nd.n2.x, nd.n2.y, sr, bound, &e0);
+            bool h1 = slab2(nd.n1.x, nd.n1.y, nd.n1.z, nd.n1.w, nd.n2.z, nd.n2.w, sr, bound, &e1);
+            int c0 = __float_as_int(nd.n3.x), c1 = __float_as_int(nd.n3.y);
+            if (h0 && h1) {
+                bool swap = e1 < e0;
+                int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+                STK(sp) = farc; sp++;
+                cur = nearc;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else {
+                if (sp == sp_base) break;
+                sp--; cur = STK(sp);
+            }
+        } else {
+            uint32_t code = (uint32_t)~cur;
+            uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
+            for (uint32_t i = 0; i < count; i++) {
+                const DTri tr = tris[first + i];
+                float t; uint32_t side;
+                if (ray_triangle(mk3(tr.v0.x, tr.v0.y, tr.v0.z), mk3(tr.v1.x, tr.v1.y, tr.v1.z),
+                                 mk3(tr.v2.x, tr.v2.y, tr.v2.z), ray, &t, &side)) {
+                    uint32_t face = __float_as_uint(tr.v0.w);
+                    if (!best.found || t < best.t || (t == best.t && face < best.face)) {
+                        best.found = true; best.t = t; best.slot = first + i; best.face = face; best.side = side;
+                    }
+                }
+            }
+            if (sp == sp_base) break;
+            sp--; cur = STK(sp);
+        }
+    }
+    *out = best;
+}
+
+// Shadow query of one mesh: is there ANY hit, and is there one with toi <= limit?
+// Stops at the first hit within the limit.
+RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, float limit,
+                     int* s_stack, int sp_base, bool* found_any, bool* found_within) {
+    bool any = false, within = false;
+    SlabRay sr; sr.o = ray.o; sr.inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    const DNode* nodes = sc.nodes + it.node_base;
+    const DTri* tris = sc.tris + it.tri_base;
+    int sp = sp_base;
+    int cur = it.root;
+    for (;;) {
+        if (cur >= 0) {
+            const DNode nd = nodes[cur];
+            // until some hit is known every box matters; afterwards only boxes that can
+            // still hold a hit within the limit
+            float bound = any ? limit : RR_FLT_MAX;
+            float e0, e1;
+            bool h0 = slab2(nd.n0.x, nd.n0.y, nd.n0.z, nd.n0.w, nd.n2.x, nd.n2.y, sr, bound, &e0);
+            bool h1 = slab2(nd.n1.x, nd.n1.y, nd.n1.z, nd.n1.w, nd.n2.z, nd.n2.w, sr, bound, &e1);
+            int c0 = __float_as_int(nd.n3.x), c1 = __float_as_int(nd.n3.y);
+            if (h0 && h1) {
+                bool swap = e1 < e0;
+                int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+                STK(sp) = farc; sp++;
+                cur = nearc;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else {
+                if (sp == sp_base) break;
+                sp--; cur = STK(sp);
+            }
+        } else {
+            uint32_t code = (uint32_t)~cur;
+            uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
+            for (uint32_t i = 0; i < count; i++) {
+                const DTri tr = tris[first + i];
+                float t; uint32_t side;
+                if (ray_triangle(mk3(tr.v0.x, tr.v0.y, tr.v0.z), mk3(tr.v1.x, tr.v1.y, tr.v1.z),
+                                 mk3(tr.v2.x, tr.v2.y, tr.v2.z), ray, &t, &side)) {
+                    any = true;
+                    if (t <= limit) within = true;
+                }
+            }
+            if (within || sp == sp_base) break;
+            sp--; cur = STK(sp);
+        }
+    }
+    *found_any = any; *found_within = within;
+}
+
+// ---------------------------------------------------------------------------
+// Raytracing::trace (reference src/raytracing.rs:429-490) per item
+// ---------------------------------------------------------------------------
+// candidate filter of :454 on the texture-less material cache
+RR_DEV bool item_passes(uint32_t flags, bool for_shadow, uint32_t depth) {
+    if (!(flags & RR_IF_VISIBLE)) return false;
+    if (!(flags & RR_IF_CACHE_ALPHA_POS)) return false;
+    if (for_shadow && !(flags & RR_IF_CACHE_CAST_SHADOW)) return false;
+    if ((flags & RR_IF_CACHE_REFL_ONLY) && !(depth > 1u)) return false;
+    return true;
+}
+
+struct Closest { float t; int item; uint32_t face; float key; bool found; };
+
+// The reference sorts candidates by bbox distance (stable) and keeps strictly
+// smaller toi, so among equal toi the smaller (bbox distance, item index) wins.
+RR_DEV void closest_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t depth,
+                         int* s_stack, int sp_base, Closest* best) {
+    const DItem& it = sc.items[idx];
+    uint32_t flags = it.flags;
+    if (!item_passes(flags, false, depth)) return;
+    LRay lr = inverse_ray(it, o, d, sc.general_w != 0u);
+    bool solid = (flags & RR_IF_SOLID_BASE) != 0u;
+    float key;
+    if (!aabb_cast(it.bmin, it.bmax, lr, solid, &key)) return;
+    if (key != key) return; // NaN distance: treated as a miss (the reference panics)
+    float t; uint32_t face;
+    if (flags & RR_IF_SPHERE) {
+        bool inside;
+        if (!ray_ball(it.radius, lr, solid, &t, &inside)) return;
+        face = 0u;
+    } else {
+        if (it.n_tris == 0u) return;
+        TriBest tb;
+        blas_closest(sc, it, lr, best->found ? best->t : RR_FLT_MAX, s_stack, sp_base, &tb);
+        if (!tb.found) return;
+        t = tb.t;
+        face = tb.slot | (tb.side << 30); // bit31 back face, bit30 negated normal
+    }
+    bool better = !best->found || t < best->t ||
+                  (t == best->t && (key < best->key || (key == best->key && idx < best->item)));
+    if (better) { best->found = true; best->t = t; best->item = idx; best->face = face; best->key = key; }
+}
+
+RR_DEV void trace_closest_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, int* s_stack, Closest* best) {
+    best->found = false; best->t = RR_FLT_MAX; best->item = -1; best->face = 0u; best->key = 0.0f;
+    if (!sc.use_tlas) {
+        for (uint32_t i = 0; i < sc.n_items; i++) closest_item(sc, (int)i, o, d, depth, s_stack, 0, best);
+        return;
+    }
+    // top level: world-space boxes over items (stands in for Scene::get_possible_hits_by_ray,
+    // reference src/scene.rs:1715-1722; any conservative candidate set gives the same result)
+    SlabRay sr; sr.o = o; sr.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const DNode* nodes = sc.nodes + sc.tlas_node_base;
+    int sp = 0;
+    int cur = sc.tlas_root;
+    for (;;) {
+        if (cur >= 0) {
+            const DNode nd = nodes[cur];
+            float bound = best->found ? best->t : RR_FLT_MAX;
+            float e0, e1;
+            bool h0 = slab2(nd.n0.x, nd.n0.y, nd.n0.z, nd.n0.w, nd.n2.x, nd.n2.y, sr, bound, &e0);
+            bool h1 = slab2(nd.n1.x, nd.n1.y, nd.n1.z, nd.n1.w, nd.n2.z, nd.n2.w, sr, bound, &e1);
+            int c0 = __float_as_int(nd.n3.x), c1 = __float_as_int(nd.n3.y);
+            if (h0 && h1) {
+                bool swap = e1 < e0;
+                STK(sp) = swap ? c0 : c1; sp++;
+                cur = swap ? c1 : c0;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else { if (sp == 0) break; sp--; cur = STK(sp); }
+        } else {
+            uint32_t code = (uint32_t)~cur;
+            uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
+            for (uint32_t i = 0; i < count; i++) closest_item(sc, (int)(first + i), o, d, depth, s_stack, sp, best);
+            if (sp == 0) break;
+            sp--; cur = STK(sp);
+        }
+    }
+}
+
+// Shadow rays stop at the first ITEM (in bbox-distance order) that is hit at all
+// (reference src/raytracing.rs:483-486), not at the nearest hit.
+struct ShadowSel { float key; int item; bool found; bool within; float t; uint32_t face; };
+
+RR_DEV void shadow_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t depth, float limit,
+                        int* s_stack, int sp_base, ShadowSel* sel) {
+    const DItem& it = sc.items[idx];
+    uint32_t flags = it.flags;
+    if (!item_passes(flags, true, depth)) return;
+    LRay lr = inverse_ray(it, o, d, sc.general_w != 0u);
+    float key;
+    if (!aabb_cast(it.bmin, it.bmax, lr, false, &key)) return; // for_shadow forces solid = false
+    if (key != key) return;
+    if (sel->found && !(key < sel->key || (key == sel->key && idx < sel->item))) return;
+    bool any = false, within = false; float t = 0.0f; uint32_t face = 0u;
+    if (flags & RR_IF_SPHERE) {
+        bool inside;
+        if (ray_ball(it.radius, lr, false, &t, &inside)) { any = true; within = t <= limit; }
+    } else if (it.n_tris != 0u) {
+        if (flags & RR_IF_OCCLUDER_ALPHA_TEX) { // the occluder's alpha map needs the true nearest hit
+            TriBest tb;
+            blas_closest(sc, it, lr, RR_FLT_MAX, s_stack, sp_base, &tb);
+            if (tb.found) { any = true; t = tb.t; within = t <= limit; face = tb.face + ((tb.side & 2u) ? it.n_tris : 0u); }
+        } else {
+            blas_any(sc, it, lr, limit, s_stack, sp_base, &any, &within);
+        }
+    }
+    if (any) { sel->found = true; sel->key = key; sel->item = idx; sel->within = within; sel->t = t; sel->face = face; }
+}
+
+RR_DEV void trace_shadow_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, float limit, int* s_stack, ShadowSel* sel) {
+    sel->found = false; sel->within = false; sel->key = 0.0f; sel->item = -1; sel->t = 0.0f; sel->face = 0u;
+    if (!sc.use_tlas) {
+        for (uint32_t i = 0; i < sc.n_items; i++) shadow_item(sc, (int)i, o, d, depth, limit, s_stack, 0, sel);
+        return;
+    }
+    SlabRay sr; sr.o = o; sr.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const DNode* nodes = sc.nodes + sc.tlas_node_base;
+    int sp = 0;
+    int cur = sc.tlas_root;
+    for (;;) {
+        if (cur >= 0) {
+            const DNode nd = nodes[cur];
+            // an item whose world box starts beyond the selected item's key cannot precede it
+            float bound = sel->found ? sel->key * 1.00001f + 1e-6f : RR_FLT_MAX;
+            float e0, e1;
+            bool h0 = slab2(nd.n0.x, nd.n0.y, nd.n0.z, nd.n0.w, nd.n2.x, nd.n2.y, sr, bound, &e0);
+            bool h1 = slab2(nd.n1.x, nd.n1.y, nd.n1.z, nd.n1.w, nd.n2.z, nd.n2.w, sr, bound, &e1);
+            int c0 = __float_as_int(nd.n3.x), c1 = __float_as_int(nd.n3.y);
+            if (h0 && h1) {
+                bool swap = e1 < e0;
+                STK(sp) = swap ? c0 : c1; sp++;
+                cur = swap ? c1 : c0;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else { if (sp == 0) break; sp--; cur = STK(sp); }
+        } else {
+            uint32_t code = (uint32_t)~cur;
+            uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
+            for (uint32_t i = 0; i < count; i++) shadow_item(sc, (int)(first + i), o, d, depth, limit, s_stack, sp, sel);
+            if (sp == 0) break;
+            sp--; cur = STK(sp);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// textures: reference src/raytracing.rs:629-675, src/shape/mod.rs:510-629
+// ---------------------------------------------------------------------------
+RR_DEV float4 texel(const DSceneView& sc, const DTexture& t, uint32_t x, uint32_t y) {
+    uint32_t p = sc.texels[t.offset + (uint64_t)y * t.width + x];
+    return make_float4(c_u8_to_f32[p & 255u], c_u8_to_f32[(p >> 8) & 255u], c_u8_to_f32[(p >> 16) & 255u], c_u8_to_f32[p >> 24]);
+}
+RR_DEV uint32_t tex_wrap(float val, uint32_t bound) {
+    int32_t sb = (int32_t)bound;
+    int32_t w = as_i32(val * (float)bound) % sb;
+    return (w < 0) ? (uint32_t)(w + sb) : (uint32_t)w;
+}
+RR_DEV float lerp1(float a, float b, float f) { return a + f * (b - a); } // helper::interpolate
+RR_DEV float4 tex_bilinear(const DSceneView& sc, const DTexture& t, float u, float v) {
+    uint32_t width = t.width, height = t.height;
+    float x = u * (float)width, y = v * (float)height;
+    if (x < 0.0f) x = x + (float)width;
+    if (y < 0.0f) y = y + (float)height;
+    uint32_t x0 = as_u32(floorf(x)), x1 = as_u32(ceilf(x));
+    uint32_t y0 = as_u32(floorf(y)), y1 = as_u32(ceilf(y));
+    if (x0 >= width) x0 = width - 1u;
+    if (y0 >= height) y0 = height - 1u;
+    if (x1 >= width) x1 = width - 1u;
+    if (y1 >= height) y1 = height - 1u;
+    float fx = x - (float)x0, fy = y - (float)y0;
+    float4 p0 = texel(sc, t, x0, y0), p1 = texel(sc, t, x1, y0), p2 = texel(sc, t, x0, y1), p3 = texel(sc, t, x1, y1);
+    float4 a = make_float4(lerp1(p0.x, p1.x, fx), lerp1(p0.y, p1.y, fx), lerp1(p0.z, p1.z, fx), lerp1(p0.w, p1.w, fx));
+    float4 b = make_float4(lerp1(p2.x, p3.x, fx), lerp1(p2.y, p3.y, fx), lerp1(p2.z, p3.z, fx), lerp1(p2.w, p3.w, fx));
+    return make_float4(lerp1(a.x, b.x, fy), lerp1(a.y, b.y, fy), lerp1(a.z, b.z, fy), lerp1(a.w, b.w, fy));
+}
+// get_tex_color: false = None
+RR_DEV bool tex_color(const DSceneView& sc, const DMaterial& m, bool has_uv, f2 uv, int slot, float4* out) {
+    int ti = m.tex[slot];
+    if (ti < 0 || !has_uv) return false;
+    const DTexture t = sc.textures[ti];
+    if (t.width == 0u) return false;
+    if (m.flags & RR_MF_NEAREST) *out = texel(sc, t, tex_wrap(uv.x, t.width), tex_wrap(uv.y, t.height));
+    else *out = tex_bilinear(sc, t, uv.x, uv.y);
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// uv / normals: reference src/shape/mesh.rs:105-161, :204-259; src/shape/sphere.rs:69-99
+// ---------------------------------------------------------------------------
+RR_DEV void area_weights(f3 a, f3 b, f3 c, f3 p, float* a1, float* a2, float* a3) {
+    f3 f1 = a - p, f2v = b - p, f3v = c - p;
+    float area = norm3(cross3(a - b, a - c));
+    *a1 = norm3(cross3(f2v, f3v)) / area;
+    *a2 = norm3(cross3(f3v, f1)) / area;
+    *a3 = norm3(cross3(f1, f2v)) / area;
+}
+RR_DEV f2 sphere_uv(const DItem& it, f3 hit, bool general_w) {
+    f3 p = to_local_point(it, hit, general_w);
+    float theta = rr_atan2(-(p.z - 0.0f), p.x - 0.0f);
+    float u = (theta + RR_PI_F) / (2.0f * RR_PI_F);
+    float phi = rr_acos((-(p.y - 0.0f)) / it.radius);
+    float v = phi / RR_PI_F;
+    f2 r; r.x = u; r.y = -v; return r;
+}
+RR_DEV f2 mesh_uv(const DSceneView& sc, const DItem& it, uint32_t slot, f3 hit, bool general_w) {
+    f2 r; r.x = 0.0f; r.y = 0.0f;
+    const DTriAttr at = sc.attrs[it.tri_base + slot];
+    if (!(__float_as_uint(at.s3.w) & 1u)) return r;
+    f3 p = to_local_point(it, hit, general_w);
+    const DTri tr = sc.tris[it.tri_base + slot];
+    float a1, a2, a3;
+    area_weights(mk3(tr.v0.x, tr.v0.y, tr.v0.z), mk3(tr.v1.x, tr.v1.y, tr.v1.z), mk3(tr.v2.x, tr.v2.y, tr.v2.z), p, &a1, &a2, &a3);
+    float ux = (at.s0.w * a1 + at.s2.w * a2) + at.s3.y * a3;
+    float uy = (at.s1.w * a1 + at.s3.x * a2) + at.s3.z * a3;
+    r.x = ux; r.y = -uy;
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// jitter (reference src/raytracing.rs:565-626) on the counter-based generator
+// ---------------------------------------------------------------------------
+struct RngKey { uint32_t seed_lo, seed_hi, pixel, sample, node; };
+RR_DEV f3 jitter(f3 dir, float spread, const RngKey& k, uint32_t stream) {
+    if (spread <= 0.0f) return dir;
+    f3 b3 = normalize3(dir);
+    f3 diff = (rr_abs(b3.x) < 0.5f) ? mk3(1.0f, 0.0f, 0.0f) : mk3(0.0f, 1.0f, 0.0f);
+    f3 b1 = normalize3(cross3(b3, diff));
+    f3 b2 = cross3(b1, b3);
+    float z_lo = rr_cos(spread * RR_PI_F);
+    if (!(z_lo < 1.0f)) return dir;
+    uint32_t r0, r1;
+    philox4x32_10(k.pixel, k.sample, k.node, stream, k.seed_lo, k.seed_hi, &r0, &r1);
+    float z = uniform_f32(r0, z_lo, 1.0f);
+    float r = sqrtf(1.0f - z * z);
+    float theta = uniform_f32(r1, -RR_PI_F, RR_PI_F);
+    float s, c;
+    rr_sincos(theta, &s, &c);
+    float x = r * c, y = r * s;
+    f3 nd = (x * b1 + y * b2) + z * b3;
+    return normalize3(nd);
+}
+
+// fresnel, reference src/raytracing.rs:535-563 (cos_i = |cos_t| as written there)
+RR_DEV float fresnel(f3 incident, f3 normal, float index) {
+    float i_dot_n = dot3(incident, normal);
+    float eta_i = 1.0f, eta_t = index;
+    if (i_dot_n > 0.0f) { eta_i = eta_t; eta_t = 1.0f; }
+    float sin_t = eta_i / eta_t * sqrtf(rs_max(1.0f - i_dot_n * i_dot_n, 0.0f));
+    if (sin_t > 1.0f) return 1.0f;
+    float cos_t = sqrtf(rs_max(1.0f - sin_t * sin_t, 0.0f));
+    float cos_i = rr_abs(cos_t);
+    float r_s = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_i * cos_t));
+    float r_p = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
+    return (r_s * r_s + r_p * r_p) / 2.0f;
+}
+
+// ---------------------------------------------------------------------------
+// accumulators
+// ---------------------------------------------------------------------------
+RR_DEV long long to_fix(float v, float scale, float clampv) {
+    if (v != v) return 0ll; // NaN contributions are dropped (divergences)
+    v = fminf(fmaxf(v, -clampv), clampv);
+    return __float2ll_rn(v * scale);
+}
+RR_DEV void accum_rgb(const DAccum& acc, uint32_t pix, float r, float g, float b) {
+    long long fr = to_fix(r, RR_FIX_SCALE, RR_FIX_CLAMP), fg = to_fix(g, RR_FIX_SCALE, RR_FIX_CLAMP), fb = to_fix(b, RR_FIX_SCALE, RR_FIX_CLAMP);
+    unsigned long long* p = (unsigned long long*)(acc.rgb + 3ull * pix);
+    if (fr) atomicAdd(p + 0, (unsigned long long)fr);
+    if (fg) atomicAdd(p + 1, (unsigned long long)fg);
+    if (fb) atomicAdd(p + 2, (unsigned long long)fb);
+}
+
+// persistent packet fetch: one atomic per wave hands out 64 consecutive queue slots
+RR_DEV uint32_t wave_fetch(uint32_t* head, uint32_t lane) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(head, (uint32_t)RR_WAVE);
+    return __shfl(base, 0) + lane;
+}
+
+// ---------------------------------------------------------------------------
+// kernel 1: primary rays (reference src/raytracing.rs:319-396)
+// ---------------------------------------------------------------------------
+RR_DEV float4 mat4_mul(const float* m, float x, float y, float z, float w) {
+    return make_float4(((m[0] * x + m[4] * y) + m[8] * z) + m[12] * w,
+                       ((m[1] * x + m[5] * y) + m[9] * z) + m[13] * w,
+                       ((m[2] * x + m[6] * y) + m[10] * z) + m[14] * w,
+                       ((m[3] * x + m[7] * y) + m[11] * z) + m[15] * w);
+}
+
+__global__ __launch_bounds__(RR_BLOCK) void k_raygen(DFrame fr, const uint32_t* __restrict__ region_xy,
+                                                     const uint16_t* __restrict__ sample_xy,
+                                                     unsigned long long first, uint32_t n_rays, DRayQueue q,
+                                                     uint32_t* q_count, unsigned long long* counters) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { *q_count = n_rays; atomicAdd(&counters[RR_CNT_PRIMARY], (unsigned long long)n_rays); }
+    if (i >= n_rays) return;
+    const unsigned long long gi = first + i; // sample-major index over the region: sample = gi / n_pix
+    uint32_t pix = (uint32_t)(gi % fr.n_region_pixels);
+    uint32_t s = (uint32_t)(gi / fr.n_region_pixels);
+    uint32_t xy = region_xy[pix];
+    float x_f = (float)(xy & 0xffffu), y_f = (float)(xy >> 16);
+    float w = (float)fr.width, h = (float)fr.height;
+    float x_step = 2.0f / w, y_step = 2.0f / h;
+    float x_i = (float)sample_xy[2u * s], y_i = (float)sample_xy[2u * s + 1u];
+    float inv_cell = 1.0f / (float)fr.cell_size;
+    float x_trans = x_step * x_i * inv_cell;
+    float y_trans = y_step * y_i * inv_cell;
+    if (fr.dof && fr.samples > 1u) { x_trans -= x_step / 2.0f; y_trans -= y_step / 2.0f; }
+    f3 origin, dir;
+    if (fr.dof) {
+        float aperture_scale = (float)fr.width / 800.0f;
+        x_trans *= fr.aperture_size * aperture_scale;
+        y_trans *= fr.aperture_size * aperture_scale;
+        float cx = ((x_f + 0.5f) / w) * 2.0f - 1.0f;
+        float cy = 1.0f - ((y_f + 0.5f) / h) * 2.0f;
+        float4 cpp = mat4_mul(fr.proj_inv, cx, cy, -1.0f, 1.0f);
+        f3 rd = mk3(cpp.x - 0.0f, cpp.y - 0.0f, cpp.z - 0.0f);
+        float4 eye = mat4_mul(fr.view_inv, 0.0f, 0.0f, 0.0f, 1.0f);
+        float4 dv = mat4_mul(fr.view_inv, rd.x, rd.y, rd.z, 0.0f);
+        float dn = sqrtf((dv.x * dv.x + dv.z * dv.z) + (dv.y * dv.y + dv.w * dv.w)); // nalgebra 4-lane dot order
+        float4 dvn = make_float4(dv.x / dn, dv.y / dn, dv.z / dn, dv.w / dn);
+        float dist = norm3(rd);
+        float f = 1.0f / (dist / (dist + fr.focal_length));
+        f3 p = mk3(eye.x + f * dvn.x, eye.y + f * dvn.y, eye.z + f * dvn.z);
+        float sx = (((x_f + 0.5f) / w) * 2.0f - 1.0f) + x_trans;
+        float sy = (1.0f - ((y_f + 0.5f) / h) * 2.0f) + y_trans;
+        float4 pp = mat4_mul(fr.proj_inv, sx, sy, -1.0f, 1.0f);
+        float4 ro = mat4_mul(fr.view_inv, pp.x, pp.y, pp.z, 1.0f);
+        origin = mk3(ro.x, ro.y, ro.z);
+        dir = mk3(p.x - ro.x, p.y - ro.y, p.z - ro.z);
+    } else {
+        float sx = (((x_f + 0.5f) / w) * 2.0f - 1.0f) + x_trans;
+        float sy = (1.0f - ((y_f + 0.5f) / h) * 2.0f) + y_trans;
+        float4 pp = mat4_mul(fr.proj_inv, sx, sy, -1.0f, 1.0f);
+        float4 o = mat4_mul(fr.view_inv, pp.x, pp.y, pp.z, 1.0f);
+        float4 d = mat4_mul(fr.view_inv, pp.x - 0.0f, pp.y - 0.0f, pp.z - 0.0f, 0.0f);
+        origin = mk3(o.x, o.y, o.z);
+        dir = mk3(d.x, d.y, d.z);
+    }
+    dir = normalize3(dir); // get_color_depth_normal_id normalises on entry (:723)
+    q.r0[i] = make_float4(origin.x, origin.y, origin.z, 1.0f);
+    q.r1[i] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(pix));
+    q.r2[i] = make_uint2(s | (1u << 16) | (1u << 24), 1u);
+}
+
+// ---------------------------------------------------------------------------
+// kernel 2: closest hit for a queue of rays
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(RR_BLOCK) void k_trace_closest(DSceneView sc, DRayQueue q, const uint32_t* __restrict__ q_count,
+                                                            uint32_t* head) {
+    __shared__ int s_stack[RR_STACK_DEPTH * RR_BLOCK];
+    const uint32_t n = *q_count;
+    const uint32_t lane = threadIdx.x & (RR_WAVE - 1);
+    for (;;) {
+        uint32_t i = wave_fetch(head, lane);
+        if (__builtin_amdgcn_readfirstlane(i) >= n) break; // whole packet beyond the end: wave-uniform exit
+        if (i < n) {
+            float4 r0 = q.r0[i], r1 = q.r1[i];
+            uint32_t depth = (q.r2[i].x >> 16) & 0xffu;
+            Closest best;
+            trace_closest_ray(sc, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), depth, s_stack, &best);
+            q.hit[i] = make_uint4(__float_as_uint(best.t), (uint32_t)(best.found ? best.item : -1), best.face, 0u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// wave-level queue allocation: ballot + prefix, one atomic per wave.  Must be
+// reached by every lane that may set `want` in the same control-flow region.
+// ---------------------------------------------------------------------------
+RR_DEV uint32_t wave_alloc(uint32_t* counter, bool want, uint32_t lane) {
+    unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return 0u;
+    int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0u;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// get_item_color, reference src/raytracing.rs:677-712
+RR_DEV float4 item_color(const DSceneView& sc, const DMaterial& m, bool has_uv, f2 uv, const float* rgb, int slot) {
+    float4 c = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+    float4 t;
+    if (tex_color(sc, m, has_uv, uv, slot, &t)) { c.x *= t.x; c.y *= t.y; c.z *= t.z; c.w *= t.w; }
+    return c;
+}
+
+// ---------------------------------------------------------------------------
+// kernel 3: shade one depth level (reference src/raytracing.rs:734-995)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(RR_BLOCK) void k_shade(DSceneView sc, DFrame fr, const uint32_t* __restrict__ region_xy,
+                                                    DRayQueue qin, const uint32_t* __restrict__ qin_count,
+                                                    uint32_t chunk_begin, uint32_t chunk_end,
+                                                    DRayQueue qout, uint32_t* qout_count,
+                                                    DShadowQueue sq, uint32_t* sq_count,
+                                                    DAccum acc, unsigned long long* counters) {
+    const uint32_t n = min(*qin_count, chunk_end);
+    const uint32_t lane = threadIdx.x & (RR_WAVE - 1);
+    const bool gw = sc.general_w != 0u;
+    uint32_t n_shaded = 0, n_shadow = 0, n_secondary = 0;
+    const uint32_t wave_global = blockIdx.x * (RR_BLOCK / RR_WAVE) + threadIdx.x / RR_WAVE;
+    const uint32_t wave_stride = gridDim.x * (RR_BLOCK / RR_WAVE) * RR_WAVE;
+    for (uint32_t base = chunk_begin + wave_global * RR_WAVE; base < n; base += wave_stride) {
+        const uint32_t i = base + lane;
+        if (i >= n) continue;
+        const uint4 hit = qin.hit[i];
+        const int item_idx = (int)hit.y;
+        if (item_idx < 0) continue; // miss: colour 0, depth 0, normal 0, id 0 (:728-732); buffers are pre-zeroed
+        n_shaded++;
+        const float4 r0 = qin.r0[i], r1 = qin.r1[i];
+        const uint2 r2 = qin.r2[i];
+        const uint32_t pix = __float_as_uint(r1.w);
+        const uint32_t meta = r2.x, node = r2.y;
+        const uint32_t sample = meta & 0xffffu, depth = (meta >> 16) & 0xffu;
+        const bool idc = ((meta >> 24) & 1u) != 0u;
+        const float thr = r0.w;
+        const DItem& it = sc.items[item_idx];
+        const DMaterial& m = sc.materials[it.material];
+        const f3 ro = mk3(r0.x, r0.y, r0.z), rd = mk3(r1.x, r1.y, r1.z);
+        const float hit_dist = __uint_as_float(hit.x);
+        const f3 hit_point = ro + (rd * hit_dist);
+        const uint32_t slot = hit.z & 0x3fffffffu;
+        const bool back = (hit.z >> 31) != 0u, neg = ((hit.z >> 30) & 1u) != 0u;
+
+        // ---- world normal: Shape::intersect (mesh.rs:76-98, sphere.rs:61-65)
+        f3 normal;
+        if (it.flags & RR_IF_SPHERE) {
+            LRay lr = inverse_ray(it, ro, rd, gw);
+            float t2 = 0.0f; bool inside = false;
+            ray_ball(it.radius, lr, (it.flags & RR_IF_SOLID_BASE) != 0u, &t2, &inside);
+            f3 nl = normalize3(lr.o + lr.d * t2);
+            normal = to_world_normal(it, inside ? -nl : nl);
+        } else {
+            const DTri tr = sc.tris[it.tri_base + slot];
+            const f3 a = mk3(tr.v0.x, tr.v0.y, tr.v0.z), b = mk3(tr.v1.x, tr.v1.y, tr.v1.z), c = mk3(tr.v2.x, tr.v2.y, tr.v2.z);
+            if (it.flags & RR_IF_SMOOTH) {
+                const DTriAttr at = sc.attrs[it.tri_base + slot];
+                f3 p = to_local_point(it, hit_point, gw);
+                float a1, a2, a3;
+                area_weights(a, b, c, p, &a1, &a2, &a3);
+                f3 p1 = mk3(at.s0.x, at.s0.y, at.s0.z) * a1, p2 = mk3(at.s1.x, at.s1.y, at.s1.z) * a2, p3 = mk3(at.s2.x, at.s2.y, at.s2.z) * a3;
+                normal = to_world_normal(it, mk3(p1.x + p2.x + p3.x, p1.y + p2.y + p3.y, p1.z + p2.z + p3.z));
+                if (back) normal = -normal;
+            } else {
+                f3 ng = normalize3(cross3(b - a, c - a));
+                normal = to_world_normal(it, neg ? -ng : ng);
+            }
+            if (it.flags & RR_IF_FLIP_NORMALS) normal = -normal;
+        }
+        // ---- aux outputs of the root node (:742-744, :400-402)
+        if (depth == 1u) {
+            atomicAdd((unsigned long long*)(acc.depth + pix), (unsigned long long)to_fix(hit_dist, RR_DEPTH_SCALE, 1.0e9f));
+            unsigned long long* np = (unsigned long long*)(acc.normal + 3ull * pix);
+            atomicAdd(np + 0, (unsigned long long)to_fix(normal.x, RR_FIX_SCALE, RR_FIX_CLAMP));
+            atomicAdd(np + 1, (unsigned long long)to_fix(normal.y, RR_FIX_SCALE, RR_FIX_CLAMP));
+            atomicAdd(np + 2, (unsigned long long)to_fix(normal.z, RR_FIX_SCALE, RR_FIX_CLAMP));
+        }
+        // ---- uv (:749-754)
+        bool has_uv = false; f2 uv; uv.x = 0.0f; uv.y = 0.0f;
+        if (m.flags & RR_MF_ANY_TEX) {
+            uv = (it.flags & RR_IF_SPHERE) ? sphere_uv(it, hit_point, gw) : mesh_uv(sc, it, slot, hit_point, gw);
+            has_uv = true;
+        }
+        f3 surface_normal = normal;
+        float4 tc;
+        // ---- normal mapping (:757-784)
+        if (tex_color(sc, m, has_uv, uv, 3, &tc)) {
+            f3 tangent = cross3(normal, mk3(0.0f, 1.0f, 0.0f));
+            if (norm3(tangent) <= 0.0001f) tangent = cross3(normal, mk3(0.0f, 0.0f, 1.0f));
+            tangent = normalize3(tangent);
+            f3 bitangent = normalize3(cross3(normal, tangent));
+            f3 nm = mk3((tc.x * 2.0f) - 1.0f, (tc.y * 2.0f) - 1.0f, (tc.z * 2.0f) - 1.0f);
+            nm.x *= m.normal_map_strength; nm.y *= m.normal_map_strength;
+            nm = normalize3(nm);
+            f3 t;
+            t.x = (tangent.x * nm.x + bitangent.x * nm.y) + normal.x * nm.z;
+            t.y = (tangent.y * nm.x + bitangent.y * nm.y) + normal.y * nm.z;
+            t.z = (tangent.z * nm.x + bitangent.z * nm.y) + normal.z * nm.z;
+            surface_normal = normalize3(t);
+        }
+        // the generator is keyed on the FRAME pixel (y * width + x), never on the region slot
+        const uint32_t xy = region_xy[pix];
+        RngKey rk; rk.seed_lo = fr.seed_lo; rk.seed_hi = fr.seed_hi;
+        rk.pixel = (xy >> 16) * fr.width + (xy & 0xffffu); rk.sample = sample; rk.node = node;
+        const bool mc = fr.monte_carlo != 0u && (m.flags & RR_MF_MONTE_CARLO) != 0u;
+        // ---- roughness (:787-798)
+        {
+            bool has_rtc = tex_color(sc, m, has_uv, uv, 5, &tc);
+            if (mc && (m.roughness > 0.0f || has_rtc)) {
+                float roughness = m.roughness;
+                if (has_rtc) roughness = (1.0f / RR_PI_F / 2.0f) * tc.x;
+                surface_normal = jitter(surface_normal, roughness, rk, 0u);
+            }
+        }
+        // ---- colours and alpha (:801-811)
+        const float4 ambient_color = item_color(sc, m, has_uv, uv, m.ambient, 1);
+        const float4 base_color = item_color(sc, m, has_uv, uv, m.base, 0);
+        const float4 specular_color = item_color(sc, m, has_uv, uv, m.specular, 2);
+        float alpha = m.alpha * base_color.w;
+        if (tex_color(sc, m, has_uv, uv, 4, &tc)) alpha *= tc.x;
+
+        // ---- everything after the light loop that does not depend on it (:922-991)
+        const float kr = fresnel(rd, surface_normal, m.refraction_index);
+        float reflectivity = m.reflectivity;
+        if (tex_color(sc, m, has_uv, uv, 7, &tc)) reflectivity = tc.x;
+        const bool may_recurse = depth <= fr.max_recursion;
+        const bool spawn_refl = reflectivity > 0.0f && may_recurse;
+        bool spawn_refr = false;
+        f3 refr_o = mk3(0.0f, 0.0f, 0.0f), refr_d = mk3(0.0f, 0.0f, 0.0f);
+        float a_mul = 1.0f; // the factor `color * alpha` applies to what is already in `color`
+        if (alpha < 1.0f && may_recurse) {
+            // create_transmission (:500-533)
+            f3 ref_n = surface_normal;
+            float eta_t = m.refraction_index, eta_i = 1.0f;
+            float i_dot_n = dot3(rd, surface_normal);
+            if (i_dot_n < 0.0f) { i_dot_n = -i_dot_n; }
+            else { ref_n = -surface_normal; eta_t = 1.0f; eta_i = m.refraction_index; }
+            float eta = eta_i / eta_t;
+            float k = 1.0f - (eta * eta) * (1.0f - i_dot_n * i_dot_n);
+            if (!(k < 0.0f)) {
+                spawn_refr = true;
+                refr_o = hit_point + (ref_n * -0.001f);
+                refr_d = ((rd + i_dot_n * ref_n) * eta) - (ref_n * sqrtf(k));
+                a_mul = alpha;
+            }
+        } else if (alpha < 1.0f) {
+            a_mul = alpha;
+        }
+        const float fog_amount = rs_min(fr.fog_density * hit_dist, 1.0f);
+        float ao = 1.0f;
+        if (tex_color(sc, m, has_uv, uv, 6, &tc)) ao = tc.x;
+        const float g = (1.0f - fog_amount) * ao;
+        const float w_light = thr * ((1.0f - reflectivity) * a_mul * g);
+        const float w_refl = thr * (reflectivity * a_mul * g);
+        const float w_refr = thr * (((kr < 1.0f) ? ((1.0f - kr) * (1.0f - alpha)) : (1.0f - alpha)) * g);
+
+        // ---- constant part: fog colour and ambient / emissive (:977-994)
+        {
+            float fa = fog_amount * ao;
+            accum_rgb(acc, pix, thr * (fr.fog_color[0] * fa + ambient_color.x), thr * (fr.fog_color[1] * fa + ambient_color.y),
+                      thr * (fr.fog_color[2] * fa + ambient_color.z));
+        }
+        // ---- object id (:744, :966-969): the last sample's id, passed through fully transparent hits
+        const bool child_idc = idc && spawn_refr && approx_equal(alpha, 0.0f);
+        if (idc && !child_idc && sample + 1u == fr.samples) acc.object_id[pix] = it.id;
+
+        // ---- lights (:814-920)
+        const f3 view_dir = normalize3(-rd);
+        for (uint32_t li = 0; li < sc.n_lights; li++) {
+            const DLight& L = sc.lights[li];
+            if (L.type & 0x80u) continue; // disabled
+            const f3 lpos = mk3(L.pos[0], L.pos[1], L.pos[2]), ldir = mk3(L.dir[0], L.dir[1], L.dir[2]);
+            f3 to_light;
+            if (L.type == 0u) to_light = normalize3(-ldir);
+            else to_light = normalize3(lpos - hit_point);
+            const float dot_light = rs_max(dot3(surface_normal, to_light), 0.0f);
+            const f3 ml = -to_light;
+            const f3 reflect_dir = ml - ((2.0f * dot3(surface_normal, ml)) * surface_normal);
+            const float spec_dot = rs_max(dot3(reflect_dir, view_dir), 0.0f);
+            const float light_power = powf(spec_dot, m.shininess);
+            float intensity;
+            float limit = RR_FLT_MAX;
+            if (L.type == 0u) {
+                intensity = L.intensity;
+            } else {
+                const float r2 = norm3(lpos - hit_point);
+                limit = r2;
+                intensity = L.intensity / (4.0f * RR_PI_F * r2);
+                if (L.type == 2u) {
+                    const float dd = dot3(-to_light, normalize3(ldir));
+                    if (rr_acos(dd) > L.max_angle) intensity = 0.0f;
+                }
+            }
+            const float cr = ((L.color[0] * (specular_color.x * light_power + base_color.x * dot_light)) * intensity) * w_light;
+            const float cg = ((L.color[1] * (specular_color.y * light_power + base_color.y * dot_light)) * intensity) * w_light;
+            const float cb = ((L.color[2] * (specular_color.z * light_power + base_color.z * dot_light)) * intensity) * w_light;
+            const bool nonzero = (cr != 0.0f) || (cg != 0.0f) || (cb != 0.0f);
+            const bool want_shadow = (m.flags & RR_MF_RECEIVE_SHADOW) != 0u && nonzero;
+            if (!(m.flags & RR_MF_RECEIVE_SHADOW) && nonzero) accum_rgb(acc, pix, cr, cg, cb);
+            const uint32_t si = wave_alloc(sq_count, want_shadow, lane);
+            if (want_shadow) {
+                f3 so = hit_point + (surface_normal * 0.001f);
+                f3 sd = to_light;
+                if (mc) sd = jitter(sd, m.shadow_softness, rk, 1u + li);
+                sq.s0[si] = make_float4(so.x, so.y, so.z, limit);
+                sq.s1[si] = make_float4(sd.x, sd.y, sd.z, m.alpha);
+                sq.s2[si] = make_float4(cr, cg, cb, __uint_as_float(pix));
+                sq.s3[si] = make_uint4((uint32_t)item_idx, depth, 0u, 0u);
+                n_shadow++;
+            }
+        }
+
+        // ---- children (:938-971), compacted into the next level's queue
+        const uint32_t child_meta = sample | ((depth + 1u) << 16);
+        {
+            const uint32_t oi = wave_alloc(qout_count, spawn_refl, lane);
+            if (spawn_refl) {
+                // create_reflection (:492-498)
+                f3 o2 = hit_point + (surface_normal * 0.001f);
+                f3 d2 = normalize3(rd - ((2.0f * dot3(rd, surface_normal)) * surface_normal));
+                qout.r0[oi] = make_float4(o2.x, o2.y, o2.z, w_refl);
+                qout.r1[oi] = make_float4(d2.x, d2.y, d2.z, __uint_as_float(pix));
+                qout.r2[oi] = make_uint2(child_meta, node * 2u);
+                n_secondary++;
+            }
+        }
+        {
+            const uint32_t oi = wave_alloc(qout_count, spawn_refr, lane);
+            if (spawn_refr) {
+                f3 d2 = normalize3(refr_d);
+                qout.r0[oi] = make_float4(refr_o.x, refr_o.y, refr_o.z, w_refr);
+                qout.r1[oi] = make_float4(d2.x, d2.y, d2.z, __uint_as_float(pix));
+                qout.r2[oi] = make_uint2(child_meta | (child_idc ? (1u << 24) : 0u), node * 2u + 1u);
+                n_secondary++;
+            }
+        }
+    }
+    // per-wave reduction of the work counters
+    for (int off = 32; off > 0; off >>= 1) {
+        n_shaded += __shfl_down(n_shaded, off);
+        n_shadow += __shfl_down(n_shadow, off);
+        n_secondary += __shfl_down(n_secondary, off);
+    }
+    if (lane == 0) {
+        if (n_shaded) atomicAdd(&counters[RR_CNT_SHADED], (unsigned long long)n_shaded);
+        if (n_shadow) atomicAdd(&counters[RR_CNT_SHADOW], (unsigned long long)n_shadow);
+        if (n_secondary) atomicAdd(&counters[RR_CNT_SECONDARY], (unsigned long long)n_secondary);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// kernel 4: shadow rays of one shade chunk (reference src/raytracing.rs:872-914)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(RR_BLOCK) void k_trace_shadow(DSceneView sc, DShadowQueue sq, const uint32_t* __restrict__ sq_count,
+                                                           uint32_t* head, DAccum acc) {
+    __shared__ int s_stack[RR_STACK_DEPTH * RR_BLOCK];
+    const uint32_t n = *sq_count;
+    const uint32_t lane = threadIdx.x & (RR_WAVE - 1);
+    const bool gw = sc.general_w != 0u;
+    for (;;) {
+        uint32_t i = wave_fetch(head, lane);
+        if (__builtin_amdgcn_readfirstlane(i) >= n) break;
+        if (i < n) {
+            const float4 s0 = sq.s0[i], s1 = sq.s1[i], s2 = sq.s2[i];
+            const uint4 s3 = sq.s3[i];
+            const f3 o = mk3(s0.x, s0.y, s0.z), d = mk3(s1.x, s1.y, s1.z);
+            ShadowSel sel;
+            trace_shadow_ray(sc, o, d, s3.y, s0.w, s_stack, &sel);
+            float factor = 1.0f;
+            if (sel.found && sel.within) {
+                float shadow_source_alpha = s1.w; // the RECEIVER's material.alpha (:898)
+                const DItem& occ = sc.items[sel.item];
+                if (occ.flags & RR_IF_OCCLUDER_ALPHA_TEX) {
+                    // the reference evaluates the RECEIVER's get_uv with the occluder's face id (:905)
+                    const DItem& rcv = sc.items[s3.x];
+                    const f3 shp = o + (d * sel.t);
+                    f2 uv;
+                    if (rcv.flags & RR_IF_SPHERE) uv = sphere_uv(rcv, shp, gw);
+                    else if (rcv.n_tris != 0u) uv = mesh_uv(sc, rcv, sc.face_slot[rcv.tri_base + sel.face % rcv.n_tris], shp, gw);
+                    else { uv.x = 0.0f; uv.y = 0.0f; }
+                    float4 tc;
+                    if (tex_color(sc, sc.materials[occ.material], true, uv, 4, &tc)) shadow_source_alpha *= tc.x;
+                }
+                factor = 1.0f - shadow_source_alpha;
+            }
+            accum_rgb(acc, __float_as_uint(s2.w), s2.x * factor, s2.y * factor, s2.z * factor);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// kernel 5: resolve accumulators into PixelData (reference src/raytracing.rs:406-426)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(RR_BLOCK) void k_resolve(DFrame fr, const uint32_t* __restrict__ region_xy, DAccum acc,
+                                                      uint8_t* rgba8, float* normal, float* depth, uint32_t* object_id,
+                                                      uint32_t frame_layout) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= fr.n_region_pixels) return;
+    uint32_t o = p;
+    if (frame_layout) { uint32_t xy = region_xy[p]; o = (xy >> 16) * fr.width + (xy & 0xffffu); }
+    const double inv_fix = 1.0 / 16777216.0;
+    const float n = (float)fr.samples;
+    float c[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float sum = (float)((double)acc.rgb[3ull * p + k] * inv_fix);
+        float v = sum / n;
+        c[k] = rs_min(v, 1.0f);
+    }
+    uint32_t r, g, b;
+    if (fr.gamma) {
+        const float ig = 1.0f / 2.2f;
+        r = as_u8(powf(c[0], ig) * 255.0f); g = as_u8(powf(c[1], ig) * 255.0f); b = as_u8(powf(c[2], ig) * 255.0f);
+    } else {
+        r = as_u8(c[0] * 255.0f); g = as_u8(c[1] * 255.0f); b = as_u8(c[2] * 255.0f);
+    }
+    ((uint32_t*)rgba8)[o] = r | (g << 8) | (b << 16) | (255u << 24);
+    if (normal) {
+        f3 nn = mk3((float)((double)acc.normal[3ull * p] * inv_fix) / n, (float)((double)acc.normal[3ull * p + 1] * inv_fix) / n,
+                    (float)((double)acc.normal[3ull * p + 2] * inv_fix) / n);
+        nn = normalize3(nn); // 0/0 = NaN on all-miss pixels, as in the reference (:426)
+        normal[3ull * o] = nn.x; normal[3ull * o + 1] = nn.y; normal[3ull * o + 2] = nn.z;
+    }
+    if (depth) depth[o] = (float)((double)acc.depth[p] * (1.0 / 65536.0)) / n;
+    if (object_id) object_id[o] = acc.object_id[p];
+}
+
+// ---------------------------------------------------------------------------
+// kernel 6: gather compact per-rank buffers into frame order (multi-GPU epilogue)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(RR_BLOCK) void k_gather_frame(const uint32_t* __restrict__ src_index, uint32_t n_pixels,
+                                                           uint32_t elem_words, const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels * elem_words) return;
+    uint32_t p = i / elem_words, w = i % elem_words;
+    dst[i] = src[(uint64_t)src_index[p] * elem_words + w];
+}
+
+// ---------------------------------------------------------------------------
+// kernel 7: device self-test of the arithmetic contract (tests/test_device_math.py)
+// op: 0 sincos -> (sin, cos); 1 acos; 2 atan2(a, b); 3 a / b; 4 sqrt(a); 5 jitter(dir = (a, b, c))
+// ---------------------------------------------------------------------------
+__global__ void k_math_probe(int op, const float* a, const float* b, const float* c, int n, float* out0, float* out1, float* out2,
+                             uint32_t seed_lo, uint32_t seed_hi) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (op == 0) { float s, co; rr_sincos(a[i], &s, &co); out0[i] = s; out1[i] = co; }
+    else if (op == 1) out0[i] = rr_acos(a[i]);
+    else if (op == 2) out0[i] = rr_atan2(a[i], b[i]);
+    else if (op == 3) out0[i] = a[i] / b[i];
+    else if (op == 4) out0[i] = sqrtf(a[i]);
+    else if (op == 5) {
+        RngKey k; k.seed_lo = seed_lo; k.seed_hi = seed_hi; k.pixel = (uint32_t)i; k.sample = (uint32_t)(i & 7); k.node = 1u + (uint32_t)(i % 5);
+        f3 r = jitter(mk3(a[i], b[i], c[i]), 0.05f, k, (uint32_t)(i % 3));
+        out0[i] = r.x; out1[i] = r.y; out2[i] = r.z;
+    }
+}

@@ -219,6 +219,7 @@ class FlatScene:
         self.textures: List[np.ndarray] = []  # (H,W,4) uint8
         self.lights: List[Light] = []
         self.name = ""
+        self.meta: dict = {}  # JSON-serialisable extras: camera state, scene-file config overrides
         self._keep = None
 
     # -- ABI view -----------------------------------------------------------
@@ -295,7 +296,8 @@ class FlatScene:
 
     # -- npz round trip --------------------------------------------------------
     def save(self, path: str) -> None:
-        d = {"name": np.asarray(self.name)}
+        import json
+        d = {"name": np.asarray(self.name), "meta": np.asarray(json.dumps(self.meta))}
         d["n"] = np.asarray([len(self.items), len(self.meshes), len(self.materials), len(self.textures), len(self.lights)])
         for i, t in enumerate(self.textures):
             t = np.asarray(t, dtype=np.uint8)
@@ -324,7 +326,9 @@ class FlatScene:
     def load(cls, path: str) -> "FlatScene":
         z = np.load(path, allow_pickle=False)
         s = cls()
+        import json
         s.name = str(z["name"])
+        s.meta = json.loads(str(z["meta"])) if "meta" in z.files else {}
         ni, nm, nmat, nt, nl = [int(v) for v in z["n"]]
         for i in range(nt):
             t = z[f"tex{i}"]
