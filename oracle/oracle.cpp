@@ -336,6 +336,14 @@ static int32_t build_rec(std::vector<BuildTri>& t, uint32_t a, uint32_t b, MeshA
     return idx;
 }
 
+static void build_from_prims(std::vector<BuildTri>& t, MeshAccel& acc) {
+    acc.nodes.clear();
+    acc.nodes.reserve(t.size());
+    acc.root = t.empty() ? 0 : build_rec(t, 0, (uint32_t)t.size(), acc, 0);
+    acc.order.resize(t.size());
+    for (size_t i = 0; i < t.size(); i++) acc.order[i] = t[i].id;
+}
+
 static void build_accel(const rr_mesh& m, MeshAccel& acc) {
     std::vector<BuildTri> t(m.n_triangles);
     for (uint32_t i = 0; i < m.n_triangles; i++) {
@@ -348,11 +356,37 @@ static void build_accel(const rr_mesh& m, MeshAccel& acc) {
         }
         for (int k = 0; k < 3; k++) bt.c[k] = 0.5f * (bt.lo[k] + bt.hi[k]);
     }
-    acc.nodes.clear();
-    acc.nodes.reserve(m.n_triangles);
-    acc.root = m.n_triangles ? build_rec(t, 0, m.n_triangles, acc, 0) : 0;
-    acc.order.resize(m.n_triangles);
-    for (uint32_t i = 0; i < m.n_triangles; i++) acc.order[i] = t[i].id;
+    build_from_prims(t, acc);
+}
+
+// Scene-level BVH over the items' world AABBs (reference src/scene.rs:1674-1688;
+// Bounded::aabb, src/shape/mod.rs:48-78).  Like the `bvh` crate's traverse it returns
+// EVERY item whose box the ray touches (no distance culling); boxes are padded so the set
+// is a superset of the items that pass the exact local bbox test (divergence D4).
+static void build_scene_accel(const rr_flat_scene* fs, MeshAccel& acc) {
+    std::vector<BuildTri> t(fs->n_items);
+    for (uint32_t i = 0; i < fs->n_items; i++) {
+        const rr_item& it = fs->items[i];
+        BuildTri& bt = t[i];
+        bt.id = i;
+        for (int k = 0; k < 3; k++) { bt.lo[k] = 3e38f; bt.hi[k] = -3e38f; }
+        for (int c = 0; c < 8; c++) {
+            float px = (c & 1) ? it.bbox_max[0] : it.bbox_min[0];
+            float py = (c & 2) ? it.bbox_max[1] : it.bbox_min[1];
+            float pz = (c & 4) ? it.bbox_max[2] : it.bbox_min[2];
+            V4 w = mat_mul(it.trans, px, py, pz, 1.0f);
+            const float v[3] = {w.x, w.y, w.z};
+            for (int k = 0; k < 3; k++) { bt.lo[k] = std::min(bt.lo[k], v[k]); bt.hi[k] = std::max(bt.hi[k], v[k]); }
+        }
+        for (int k = 0; k < 3; k++) {
+            float e = (std::max(std::fabs(bt.lo[k]), std::fabs(bt.hi[k])) + (bt.hi[k] - bt.lo[k])) * 1e-5f;
+            bt.lo[k] -= e; bt.hi[k] += e;
+            if (!(bt.lo[k] == bt.lo[k])) bt.lo[k] = -3e38f;
+            if (!(bt.hi[k] == bt.hi[k])) bt.hi[k] = 3e38f;
+            bt.c[k] = 0.5f * (bt.lo[k] + bt.hi[k]);
+        }
+    }
+    build_from_prims(t, acc);
 }
 
 // conservative slab test: entry distance of [0, tmax] against a padded box
@@ -372,10 +406,20 @@ static inline bool slab(const float* lo, const float* hi, const float* o, const 
 // ---------------------------------------------------------------------------
 // scene wrapper
 // ---------------------------------------------------------------------------
+static const uint32_t BVH_MIN_ITEMS = 50; // reference src/raytracing.rs:23
+
 struct OScene {
     const rr_flat_scene* fs;
     std::vector<MeshAccel> accel;
+    MeshAccel scene_accel;
+    bool use_scene_accel = false;
     bool brute_force;
+    void prepare() {
+        accel.resize(fs->n_meshes);
+        if (brute_force) return;
+        for (uint32_t i = 0; i < fs->n_meshes; i++) build_accel(fs->meshes[i], accel[i]);
+        if (fs->n_items > BVH_MIN_ITEMS) { build_scene_accel(fs, scene_accel); use_scene_accel = true; }
+    }
 };
 
 static inline V3 load3(const float* p) { return V3{p[0], p[1], p[2]}; }
@@ -578,7 +622,38 @@ static bool trace(const OScene& sc, const Ray& ray, bool stop_on_first_hit, bool
     struct Cand { int item; float dist; };
     std::vector<Cand> hits;
     hits.reserve(fs->n_items);
-    for (uint32_t i = 0; i < fs->n_items; i++) {
+    // candidates: all items, or (more than BVH_MIN_ITEMS items) Scene::get_possible_hits_by_ray
+    std::vector<uint32_t> cand;
+    if (sc.use_scene_accel) {
+        const MeshAccel& acc = sc.scene_accel;
+        const float o[3] = {ray.origin.x, ray.origin.y, ray.origin.z};
+        const float inv[3] = {1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z};
+        int32_t stack[128]; int sp = 0;
+        int32_t cur = acc.root;
+        for (;;) {
+            if (cur < 0) {
+                uint32_t code = (uint32_t)~cur;
+                uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
+                for (uint32_t i = 0; i < count; i++) cand.push_back(acc.order[first + i]);
+            } else {
+                const BNode& nd = acc.nodes[cur];
+                CNT(nodes[tl_kind], 1);
+                float e;
+                bool h0 = slab(nd.lo[0], nd.hi[0], o, inv, 3.40282347e+38f, &e);
+                bool h1 = slab(nd.lo[1], nd.hi[1], o, inv, 3.40282347e+38f, &e);
+                if (h0 && h1) { if (sp < 127) stack[sp++] = nd.child[1]; cur = nd.child[0]; continue; }
+                if (h0) { cur = nd.child[0]; continue; }
+                if (h1) { cur = nd.child[1]; continue; }
+            }
+            if (sp == 0) break;
+            cur = stack[--sp];
+        }
+        std::sort(cand.begin(), cand.end()); // Scene.items order (D4)
+    } else {
+        cand.resize(fs->n_items);
+        for (uint32_t i = 0; i < fs->n_items; i++) cand[i] = i;
+    }
+    for (uint32_t i : cand) {
         const rr_item& it = fs->items[i];
         float dist;
         if (intersect_b_box(sc, it, ray, for_shadow, &dist)) {
@@ -1148,9 +1223,7 @@ int rro_render(const rr_flat_scene* fs, const rr_camera* cam, const rr_config* c
     OScene sc;
     sc.fs = fs;
     sc.brute_force = brute_force != 0;
-    sc.accel.resize(fs->n_meshes);
-    if (!sc.brute_force)
-        for (uint32_t i = 0; i < fs->n_meshes; i++) build_accel(fs->meshes[i], sc.accel[i]);
+    sc.prepare();
     std::vector<uint16_t> table;
     uint32_t cell_size = cell_size_for(cfg->samples);
     if (!sample_xy) {
@@ -1212,8 +1285,7 @@ int rro_render(const rr_flat_scene* fs, const rr_camera* cam, const rr_config* c
 // Raytracing::pick (reference src/raytracing.rs:237-273)
 int rro_pick(const rr_flat_scene* fs, const rr_camera* cam, int x, int y, rr_pick_result* res) {
     OScene sc; sc.fs = fs; sc.brute_force = false;
-    sc.accel.resize(fs->n_meshes);
-    for (uint32_t i = 0; i < fs->n_meshes; i++) build_accel(fs->meshes[i], sc.accel[i]);
+    sc.prepare();
     rr_config cfg; std::memset(&cfg, 0, sizeof cfg); cfg.samples = 1; cfg.focal_length = 1.0f; cfg.aperture_size = 1.0f;
     Ray ray = make_primary(*cam, cfg, x, y, 0, 0, 1);
     ray.dir = normalize(ray.dir);

@@ -1,0 +1,203 @@
+"""Host-side mirror of the reference's frame scheduler, on top of the C ABI.
+
+`Raytracing` and `RendererManager` keep the names and call surface of the
+reference (src/raytracing.rs:205-273, src/renderer.rs:38-251) so that host code
+and tests read like the reference's; what changes is that `start()` issues ONE
+frame-level call into librustray_hip.so instead of spawning num_cpus-2 worker
+threads over a shuffled queue of 2x2-pixel cells (src/renderer.rs:105-172).
+
+`TiledFrame` is the multi-GPU form (no reference counterpart):
+one process per GPU, the frame cut into interleaved tiles, every rank renders
+its tiles into a compact device buffer, one gather to rank 0 over RCCL, one
+de-interleave kernel.
+"""
+from __future__ import annotations
+
+import time
+from typing import Optional
+
+import numpy as np
+
+from . import capi
+from .camera import Camera
+from .flat import FlatScene, make_config, rr_config, rr_region
+
+
+class Raytracing:
+    """Scene + RaytracingConfig, as reference `Raytracing` (src/raytracing.rs:205-224)."""
+
+    def __init__(self, flat_scene: FlatScene, camera: Camera, device: int = 0):
+        self.flat_scene = flat_scene
+        self.camera = camera
+        self.config: rr_config = make_config()
+        cfg = flat_scene.meta.get("config") or {}
+        # a scene file's "config" block overrides whatever the caller set before load (src/scene.rs:180-198)
+        self.apply_config(**{k: v for k, v in cfg.items() if k in
+                             ("samples", "monte_carlo", "focal_length", "aperture_size", "fog_density",
+                              "max_recursion", "gamma_correction")})
+        self.device_scene = capi.DeviceScene(flat_scene, device)
+
+    def apply_config(self, **kw):
+        for k, v in kw.items():
+            if k == "fog_color":
+                self.config.fog_color[:] = list(v)
+            elif k in ("monte_carlo", "gamma_correction"):
+                setattr(self.config, k, int(bool(v)))
+            else:
+                setattr(self.config, k, v)
+
+    def render_frame(self, sample_xy=None, aux: bool = True) -> dict:
+        """All pixels of `Raytracing::render(x, y)` (src/raytracing.rs:275-427) in one call."""
+        return self.device_scene.render(self.camera.c_struct(), self.config, sample_xy=sample_xy, aux=aux)
+
+    def pick(self, x: int, y: int):
+        """Raytracing::pick (src/raytracing.rs:237-273): Some((id, distance)) or None."""
+        r = self.device_scene.pick(self.camera.c_struct(), x, y)
+        return (int(r.object_id), float(r.distance)) if r.hit else None
+
+    def close(self):
+        self.device_scene.close()
+
+
+class RendererManager:
+    """Call surface of reference `RendererManager` (src/renderer.rs:63-251)."""
+
+    def __init__(self, width: int, height: int, raytracing: Raytracing):
+        self.width, self.height = width, height
+        self.raytracing = raytracing
+        self.thread_amount = 1  # one frame-level device call replaces the worker threads
+        self._running = False
+        self._pixels_rendered = 0
+        self._start = time.time()
+        self._done_ms = 0
+        self.image = self.normals = self.depth = self.objects = None
+
+    def update_resolution(self, width: int, height: int):
+        self.width, self.height = width, height
+
+    def start(self):
+        self._start = time.time()
+        self._done_ms = 0
+        self._pixels_rendered = 0
+        self._running = True
+        self.raytracing.camera.init(self.width, self.height)
+        out = self.raytracing.render_frame()
+        # what Run::apply_pixels stores per PixelData (src/run.rs:519-541)
+        self.image, self.normals, self.depth, self.objects = out["rgba"], out["normal"], out["depth"], out["object_id"]
+        self._pixels_rendered = self.width * self.height
+        self._done_ms = int((time.time() - self._start) * 1000.0)
+
+    def stop(self):
+        self._running = False
+
+    def restart(self, width: int, height: int):
+        self.stop()
+        self.update_resolution(width, height)
+        self.start()
+
+    def is_running(self) -> bool:
+        return self._running
+
+    def is_done(self) -> bool:
+        return self._pixels_rendered == self.width * self.height
+
+    def get_rendered_pixels(self) -> int:
+        return self._pixels_rendered
+
+    def check_and_get_elapsed_time(self) -> int:
+        return self._done_ms if self._done_ms > 0 else int((time.time() - self._start) * 1000.0)
+
+
+# ---------------------------------------------------------------------------
+# multi-GPU tiling
+# ---------------------------------------------------------------------------
+def region_pixels(width: int, height: int, tile_w: int, tile_h: int, n_ranks: int, rank: int) -> np.ndarray:
+    """(n, 2) array of (x, y) in the order `rr_region` defines (include/rustray_hip.h)."""
+    tx, ty = (width + tile_w - 1) // tile_w, (height + tile_h - 1) // tile_h
+    out = []
+    for t in range(rank, tx * ty, n_ranks):
+        x0, y0 = (t % tx) * tile_w, (t // tx) * tile_h
+        x1, y1 = min(x0 + tile_w, width), min(y0 + tile_h, height)
+        ys, xs = np.mgrid[y0:y1, x0:x1]
+        out.append(np.stack([xs.ravel(), ys.ravel()], axis=1))
+    return np.concatenate(out).astype(np.int64) if out else np.zeros((0, 2), np.int64)
+
+
+class TiledFrame:
+    """One rank of a tiled multi-GPU frame.
+
+    render_fn(region, n_pixels) must return a dict of compact per-rank torch tensors
+    {"rgba": (n,4) uint8, ["normal": (n,3) f32, "depth": (n,) f32, "object_id": (n,) int32]}.
+    `gather()` collects them on rank 0 (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo"
+    on CPU) and returns full frames there, None elsewhere.
+    """
+
+    def __init__(self, width: int, height: int, rank: int, world_size: int, tile_w: int = 32, tile_h: int = 8):
+        self.width, self.height = width, height
+        self.rank, self.world_size = rank, world_size
+        self.tile_w, self.tile_h = tile_w, tile_h
+        self.counts = [len(region_pixels(width, height, tile_w, tile_h, world_size, r)) for r in range(world_size)]
+        self.max_count = max(self.counts) if self.counts else 0
+        self._index = None
+
+    def region(self) -> rr_region:
+        return rr_region(self.tile_w, self.tile_h, self.world_size, self.rank)
+
+    def n_pixels(self) -> int:
+        return self.counts[self.rank]
+
+    def _frame_index(self, device):
+        """index[y*W + x] = position of that pixel in the rank-ordered concatenation of compact buffers."""
+        import torch
+        if self._index is None or self._index.device != device:
+            idx = np.zeros(self.width * self.height, np.int64)
+            base = 0
+            for r in range(self.world_size):
+                xy = region_pixels(self.width, self.height, self.tile_w, self.tile_h, self.world_size, r)
+                idx[xy[:, 1] * self.width + xy[:, 0]] = base + np.arange(len(xy))
+                base += len(xy)
+            self._index = torch.from_numpy(idx).to(device)
+        return self._index
+
+    def gather(self, parts: dict, use_device_kernel: bool = False) -> Optional[dict]:
+        import torch
+        import torch.distributed as dist
+        out = {}
+        for key, t in parts.items():
+            t = t.reshape(self.n_pixels(), -1)
+            if self.world_size > 1:
+                pad = torch.zeros((self.max_count, t.shape[1]), dtype=t.dtype, device=t.device)
+                pad[: t.shape[0]] = t
+                gl = [torch.empty_like(pad) for _ in range(self.world_size)] if self.rank == 0 else None
+                dist.gather(pad, gl, dst=0)
+                if self.rank != 0:
+                    continue
+                cat = torch.cat([gl[r][: self.counts[r]] for r in range(self.world_size)], dim=0)
+            else:
+                cat = t
+            if use_device_kernel and cat.is_cuda:
+                frame = torch.empty((self.height * self.width, cat.shape[1]), dtype=cat.dtype, device=cat.device)
+                cat = cat.contiguous()
+                capi.deinterleave_device(self.width, self.height, self.tile_w, self.tile_h, self.world_size,
+                                         cat.shape[1] * cat.element_size(), cat.data_ptr(), frame.data_ptr(),
+                                         cat.device.index or 0, torch.cuda.current_stream().cuda_stream)
+            else:
+                frame = cat.index_select(0, self._frame_index(cat.device))
+            out[key] = frame.reshape(self.height, self.width, -1)
+        return out if self.rank == 0 else None
+
+
+def render_region_torch(device_scene: capi.DeviceScene, cam, cfg, tf: TiledFrame, aux: bool = False, sample_xy=None) -> dict:
+    """Render this rank's tiles into fresh torch CUDA tensors on torch's current stream."""
+    import torch
+    n = tf.n_pixels()
+    dev = torch.device("cuda", device_scene.device)
+    parts = {"rgba": torch.empty((n, 4), dtype=torch.uint8, device=dev)}
+    ptrs = [parts["rgba"].data_ptr(), None, None, None]
+    if aux:
+        parts["normal"] = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        parts["depth"] = torch.empty((n,), dtype=torch.float32, device=dev)
+        parts["object_id"] = torch.empty((n,), dtype=torch.int32, device=dev)
+        ptrs = [parts["rgba"].data_ptr(), parts["normal"].data_ptr(), parts["depth"].data_ptr(), parts["object_id"].data_ptr()]
+    device_scene.render_region_device(cam, cfg, tf.region(), ptrs, torch.cuda.current_stream(dev).cuda_stream, sample_xy)
+    return parts

@@ -1,0 +1,78 @@
+"""The drop-in boundary: librustray_hip.so loads and exports every function include/*.h declares;
+argument validation works without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from rustray_amd import capi
+from rustray_amd.flat import FlatScene, Item, Material, RR_ITEM_SPHERE, rr_flat_scene
+from tests.helpers import ROOT, load_scene
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "rustray_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rr_[a-z_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = C.CDLL(capi.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/rustray_hip.h but not exported"
+    assert set(capi.EXPORTS) <= set(names)
+
+
+def test_struct_sizes_match_header():
+    # sizes implied by the header's field lists (natural alignment)
+    from rustray_amd import flat
+    assert C.sizeof(flat.rr_material) == 9 * 4 + 7 * 4 + 8 * 4 + 8
+    assert C.sizeof(flat.rr_item) == 6 * 4 + 32 * 4 + 6 * 4 + 4
+    assert C.sizeof(flat.rr_light) == 11 * 4 + 4 + 4
+    assert C.sizeof(flat.rr_camera) == 8 + 128
+    assert C.sizeof(flat.rr_config) == 8 + 6 * 4 + 4 + 4
+    assert C.sizeof(flat.rr_region) == 16 and C.sizeof(flat.rr_pick_result) == 16
+
+
+def test_region_pixel_count_partitions_the_frame():
+    for (w, h, tw, th, n) in ((1280, 720, 32, 8, 8), (100, 37, 32, 8, 3), (7, 5, 8, 8, 2), (33, 9, 32, 8, 4)):
+        counts = [capi.region_pixel_count(w, h, tw, th, n, r) for r in range(n)]
+        assert sum(counts) == w * h
+    assert capi.region_pixel_count(10, 10, 0, 8, 1, 0) == 0  # invalid region -> 0
+
+
+def _create(fs_struct):
+    h = C.c_void_p(None)
+    rc = capi.lib().rr_scene_create(C.byref(fs_struct), 0, C.byref(h))
+    return rc, h, capi.lib().rr_last_error().decode()
+
+
+def test_scene_validation_without_gpu():
+    """Invalid scenes are rejected with RR_ERR_INVALID_ARGUMENT before any device is touched; a valid one
+    fails with RR_ERR_NO_DEVICE on a machine without a GPU (never a silent fallback)."""
+    fs = load_scene("spheres")
+    bad = fs.c_struct()
+    bad.abi_version = 99
+    rc, _, msg = _create(bad)
+    assert rc == -1 and "abi_version" in msg
+    fs2 = load_scene("spheres")
+    fs2.items[0].material = 1000
+    rc, _, msg = _create(fs2.c_struct())
+    assert rc == -1 and "material" in msg
+    fs3 = load_scene("monkey")
+    fs3.meshes[0].indices = fs3.meshes[0].indices.copy()
+    fs3.meshes[0].indices[5, 1] = 10 ** 6
+    rc, _, msg = _create(fs3.c_struct())
+    assert rc == -1 and "vertex index" in msg
+    fs4 = load_scene("spheres")
+    fs4.materials[fs4.items[0].material_cache].texture[0] = 0
+    rc, _, msg = _create(fs4.c_struct())
+    assert rc == -1 and "material_cache" in msg
+    if capi.device_count() == 0:
+        rc, _, msg = _create(load_scene("spheres").c_struct())
+        assert rc == -3 and "no HIP device" in msg
+    assert capi.lib().rr_scene_create(None, 0, C.byref(C.c_void_p())) == -1

@@ -1,0 +1,230 @@
+"""Parity of the HIP trace loop with the oracle, through the C ABI (run with -m gpu on an MI355X).
+
+Bar (BASELINE.json north_star): pixel RGB within +-1 LSB of the fixed-seed CPU reference; object ids
+equal; depth / normal within 1e-4 relative (they are f32 sums taken in a different order).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from rustray_amd.flat import make_config, rr_region
+from tests.golden.make_golden import CASES
+from tests.helpers import GOLDEN, camera_for, compare_frames, load_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_parity(out, ref, what=""):
+    r = compare_frames(out, ref)
+    assert r["alpha_ok"], what
+    assert r["n_rgb_over"] == 0, f"{what}: {r}"
+    assert r["n_id_diff"] == 0, f"{what}: {r}"
+    assert r["nan_mismatch"] == 0, f"{what}: {r}"
+    assert r["max_depth_rel"] < 1e-4 and r["max_normal_abs"] < 1e-4, f"{what}: {r}"
+    return r
+
+
+SMALL = [  # scene, w, h, spp, mc, seed
+    ("spheres", 256, 256, 1, False, 0),        # BASELINE C1 exactly
+    ("spheres", 96, 96, 4, True, 5),
+    ("monkey", 200, 150, 4, True, 7),          # BASELINE C2 geometry/material at reduced size
+    ("kbert", 160, 90, 2, True, 1),            # spot light, flat shading, base texture, auto camera
+    ("earth_room", 160, 90, 2, True, 2),       # 5 lights, textured sphere, planes
+    ("spheres_room", 160, 90, 2, True, 3),
+    ("monkey_room", 128, 72, 2, True, 4),
+]
+
+
+@pytest.mark.parametrize("name,w,h,spp,mc,seed", SMALL)
+def test_fixture_scenes_match_oracle(hip, oracle, name, w, h, spp, mc, seed):
+    fs = load_scene(name)
+    cam = camera_for(fs, w, h).c_struct()
+    cfg = make_config(samples=spp, monte_carlo=mc, seed=seed)
+    with hip.DeviceScene(fs, 0) as ds:
+        out = ds.render(cam, cfg)
+        st = ds.stats()
+    ref = oracle.render(fs.c_struct(), cam, cfg, n_threads=16, want_counters=True)
+    assert_parity(out, ref, name)
+    c = ref["counters"]
+    # identical path trees: same number of closest-hit rays and shaded hits as the recursive reference
+    assert st["primary_rays"] == c["rays_primary"] and st["secondary_rays"] == c["rays_secondary"]
+    assert st["shaded_hits"] == c["shaded_hits"]
+    assert st["shadow_rays"] <= c["rays_shadow"]  # zero-weight shadow rays are not traced on the device
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_golden_frames(hip, name):
+    c = CASES[name]
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    fs = load_scene(c["scene"])
+    cam = camera_for(fs, c["w"], c["h"]).c_struct()
+    cfg = make_config(samples=c["spp"], monte_carlo=c["mc"], seed=c["seed"])
+    with hip.DeviceScene(fs, 0) as ds:
+        out = ds.render(cam, cfg)
+    if c["window"]:
+        x0, y0, x1, y1 = c["window"]
+        out = {k: v[y0:y1, x0:x1] for k, v in out.items()}
+    assert_parity(out, {k: g[k] for k in g.files}, name)
+
+
+@pytest.mark.parametrize("which", ["sponza_syn", "helmet_syn", "lotus_syn"])
+def test_synthetic_stand_ins_match_oracle(hip, oracle, which):
+    """C3-C5 stand-ins at reduced size: top-level structure (> 50 items), nearest and bilinear maps, normal /
+    roughness / AO maps, glass + reflective floor, depth of field."""
+    from rustray_amd import synthetic
+    from rustray_amd.camera import Camera
+    fs = {"sponza_syn": lambda: synthetic.sponza_syn(grid=6), "helmet_syn": synthetic.helmet_syn,
+          "lotus_syn": lambda: synthetic.lotus_syn(grid=6)}[which]()
+    st = dict(fs.meta["camera"]); st["width"], st["height"] = 160, 90
+    cam = Camera.from_state(st).c_struct()
+    cd = fs.meta["config"]
+    cfg = make_config(samples=4, monte_carlo=True, seed=12, focal_length=cd.get("focal_length", 1.0), aperture_size=cd.get("aperture_size", 1.0))
+    with hip.DeviceScene(fs, 0) as ds:
+        out = ds.render(cam, cfg)
+    ref = oracle.render(fs.c_struct(), cam, cfg, n_threads=16)
+    assert_parity(out, ref, which)
+
+
+def test_config_variants(hip, oracle):
+    """fog, gamma, max_recursion 0 / 2, directional light, disabled light, no shadows, flip normals."""
+    fs = load_scene("spheres_room")
+    fs.lights[0].light_type = 0          # directional
+    fs.lights[0].dir = (0.3, -1.0, -0.2)
+    fs.lights[0].intensity = 0.8
+    fs.lights[1].enabled = False
+    fs.materials[fs.items[2].material].receive_shadow = False
+    fs.materials[fs.items[3].material].cast_shadow = False
+    fs.materials[fs.items[3].material_cache].cast_shadow = False
+    fs.items[8].flip_normals = True
+    cam = camera_for(fs, 128, 72).c_struct()
+    for kw in (dict(fog_density=0.02, fog_color=(0.2, 0.3, 0.5)), dict(gamma_correction=True), dict(max_recursion=0),
+               dict(max_recursion=2), dict(monte_carlo=False), dict(samples=1)):
+        args = dict(samples=3, monte_carlo=True, seed=21)
+        args.update(kw)
+        cfg = make_config(**args)
+        with hip.DeviceScene(fs, 0) as ds:
+            out = ds.render(cam, cfg)
+        assert_parity(out, oracle.render(fs.c_struct(), cam, cfg, n_threads=16), str(kw))
+
+
+def test_explicit_sample_table_equals_builtin(hip):
+    fs = load_scene("spheres")
+    cam = camera_for(fs, 64, 64).c_struct()
+    cfg = make_config(samples=8, monte_carlo=True, seed=1)
+    xy, _ = hip.sample_table(8)
+    with hip.DeviceScene(fs, 0) as ds:
+        a = ds.render(cam, cfg)
+        b = ds.render(cam, cfg, sample_xy=xy)
+        c = ds.render(cam, cfg, sample_xy=xy[::-1].copy())  # a different table must change MC pixels
+    assert (a["rgba"] == b["rgba"]).all()
+    assert (a["rgba"] != c["rgba"]).any()
+
+
+def test_batching_and_chunking_do_not_change_a_single_bit(hip, monkeypatch):
+    """Fixed-point accumulation: any batch size / shade chunk gives the same bits (depth and normals too)."""
+    fs = load_scene("monkey_room")
+    cam = camera_for(fs, 96, 54).c_struct()
+    cfg = make_config(samples=6, monte_carlo=True, seed=33)
+    outs = []
+    for budget, chunk in (("16384", None), ("4", "65536"), ("1", "65536")):
+        monkeypatch.setenv("RR_QUEUE_BUDGET_MB", budget)
+        if chunk:
+            monkeypatch.setenv("RR_SHADE_CHUNK", chunk)
+        with hip.DeviceScene(fs, 0) as ds:
+            outs.append(ds.render(cam, cfg))
+    for o in outs[1:]:
+        assert (o["rgba"] == outs[0]["rgba"]).all() and np.array_equal(o["depth"], outs[0]["depth"])
+        assert np.array_equal(o["normal"], outs[0]["normal"], equal_nan=True) and (o["object_id"] == outs[0]["object_id"]).all()
+
+
+def test_tiled_regions_reassemble_bit_exactly(hip):
+    """rr_render_region_device for 3 ranks + rr_deinterleave_device == rr_render of the whole frame."""
+    import torch
+    from rustray_amd.renderer import TiledFrame, render_region_torch
+    fs = load_scene("spheres")
+    w, h = 100, 61
+    cam = camera_for(fs, w, h).c_struct()
+    cfg = make_config(samples=3, monte_carlo=True, seed=8)
+    with hip.DeviceScene(fs, 0) as ds:
+        whole = ds.render(cam, cfg)
+        world = 3
+        parts = []
+        for r in range(world):
+            tf = TiledFrame(w, h, r, world, 32, 8)
+            parts.append(render_region_torch(ds, cam, cfg, tf, aux=True))
+        torch.cuda.synchronize()
+        tf0 = TiledFrame(w, h, 0, world, 32, 8)
+        for key, eb in (("rgba", 4), ("normal", 12), ("depth", 4), ("object_id", 4)):
+            cat = torch.cat([p[key].reshape(p[key].shape[0], -1) for p in parts], dim=0).contiguous()
+            frame = torch.empty((h * w, cat.shape[1]), dtype=cat.dtype, device=cat.device)
+            hip.deinterleave_device(w, h, 32, 8, world, eb, cat.data_ptr(), frame.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            got = frame.cpu().numpy().reshape(whole[key].shape)
+            ref_idx = cat.index_select(0, tf0._frame_index(cat.device)).cpu().numpy().reshape(whole[key].shape)
+            assert np.array_equal(got, ref_idx, equal_nan=True)             # device kernel == torch index path
+            assert np.array_equal(got.view(np.uint8), whole[key].view(np.uint8)), key  # == single full-frame render, bit for bit
+
+
+def test_pick_matches_oracle(hip, oracle):
+    fs = load_scene("spheres")
+    cam = camera_for(fs, 256, 256).c_struct()
+    with hip.DeviceScene(fs, 0) as ds:
+        for x, y in ((128, 128), (5, 5), (80, 128), (185, 150), (40, 80)):
+            a, b = ds.pick(cam, x, y), oracle.pick(fs.c_struct(), cam, x, y)
+            assert (a.hit, a.object_id, a.item_index) == (b.hit, b.object_id, b.item_index)
+            assert a.distance == b.distance
+
+
+def test_update_transforms_equals_new_scene(hip):
+    """rr_scene_update_transforms (animation frames) == creating the scene with those transforms."""
+    from rustray_amd.scene import get_transformation, inverse_affine
+    fs = load_scene("monkey_room")
+    cam = camera_for(fs, 96, 54).c_struct()
+    cfg = make_config(samples=2, monte_carlo=True, seed=4)
+    trans = np.stack([it.trans for it in fs.items]).copy()
+    trans[0] = get_transformation(trans[0], (0.5, 0.2, -1.0), (1.1, 1.1, 1.1), (0.0, 0.6, 0.0))
+    inv = np.stack([inverse_affine(t) for t in trans])
+    with hip.DeviceScene(fs, 0) as ds:
+        before = ds.render(cam, cfg)
+        ds.update_transforms(trans, inv)
+        moved = ds.render(cam, cfg)
+    for it, t, ti in zip(fs.items, trans, inv):
+        it.trans, it.trans_inv = t, ti
+    with hip.DeviceScene(fs, 0) as ds2:
+        fresh = ds2.render(cam, cfg)
+    assert (moved["rgba"] == fresh["rgba"]).all() and (moved["rgba"] != before["rgba"]).any()
+
+
+def test_edge_inputs(hip, oracle):
+    """1x1 and ragged frames, an empty scene, a scene whose only mesh has two triangles, samples not a power of two."""
+    fs = load_scene("spheres")
+    for w, h, spp in ((1, 1, 1), (3, 2, 5), (65, 7, 3)):
+        cam = camera_for(fs, w, h).c_struct()
+        cfg = make_config(samples=spp, monte_carlo=True, seed=2)
+        with hip.DeviceScene(fs, 0) as ds:
+            out = ds.render(cam, cfg)
+        assert_parity(out, oracle.render(fs.c_struct(), cam, cfg), f"{w}x{h}")
+    from rustray_amd.flat import FlatScene
+    empty = FlatScene(); empty.meta = fs.meta
+    cam = camera_for(fs, 16, 8).c_struct()
+    with hip.DeviceScene(empty, 0) as ds:
+        out = ds.render(cam, make_config(samples=2))
+    assert (out["rgba"][..., :3] == 0).all() and (out["rgba"][..., 3] == 255).all() and (out["object_id"] == 0).all()
+    assert np.isnan(out["normal"]).all() and (out["depth"] == 0).all()
+
+
+def test_errors_do_not_abort(hip):
+    fs = load_scene("spheres")
+    cam = camera_for(fs, 16, 16).c_struct()
+    with hip.DeviceScene(fs, 0) as ds:
+        with pytest.raises(hip.RustrayHipError) as e:
+            ds.render(cam, make_config(samples=0))
+        assert e.value.code == -1
+        with pytest.raises(hip.RustrayHipError) as e:
+            ds.render(cam, make_config(samples=1, max_recursion=40))
+        assert e.value.code == -2
+        with pytest.raises(hip.RustrayHipError):
+            ds.pick(cam, 99, 0)
+        out = ds.render(cam, make_config(samples=1))  # the handle is still usable
+        assert out["rgba"].shape == (16, 16, 4)

@@ -1,0 +1,130 @@
+"""Host logic around the hot path: flat-scene round trip, loader semantics, camera, tiling."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from rustray_amd.camera import Camera, approx_equal
+from rustray_amd.flat import FlatScene, Material, make_config
+from rustray_amd.renderer import region_pixels
+from tests.helpers import SCENES, load_scene
+
+REF = "/root/reference"
+needs_reference = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+
+
+def test_flat_scene_npz_round_trip(tmp_path):
+    fs = load_scene("spheres_room")
+    p = str(tmp_path / "x.npz")
+    fs.save(p)
+    g = FlatScene.load(p)
+    assert len(g.items) == len(fs.items) and len(g.textures) == len(fs.textures) and g.meta == fs.meta
+    for a, b in zip(fs.items, g.items):
+        assert a.id == b.id and a.kind == b.kind and a.name == b.name and np.array_equal(a.trans, b.trans)
+        assert np.array_equal(a.trans_inv, b.trans_inv) and tuple(np.float32(a.bbox_min)) == tuple(np.float32(b.bbox_min))
+    for a, b in zip(fs.materials, g.materials):
+        assert a == b
+    for a, b in zip(fs.textures, g.textures):
+        assert np.array_equal(a, b)
+
+
+def test_spheres_scene_semantics():
+    """What Scene::load leaves in memory for scene/spheres.json."""
+    fs = load_scene("spheres")
+    assert [it.id for it in fs.items] == [3, 6, 9, 12, 15, 18, 21, 24]       # ids assigned twice (src/scene.rs:440,:541)
+    assert [it.visible for it in fs.items] == [True, False, True, True, True, True, True, False]
+    assert len(fs.lights) == 1 and fs.lights[0].pos == (-2.0, 10.0, 5.0) and fs.lights[0].intensity == 200.0
+    m = fs.materials[fs.items[0].material]
+    assert m.base_color == (1.0, 0.0, 1.0) and m.specular_color == tuple(np.float32(c) * np.float32(0.8) for c in m.base_color)
+    tex = fs.materials[fs.items[5].material]
+    assert tex.texture[0] == 0 and fs.textures[0].shape == (1024, 2048, 4) and tex.roughness == float(np.float32(0.05))
+    cache = fs.materials[fs.items[5].material_cache]
+    assert cache.texture == [-1] * 8 and cache.alpha == tex.alpha            # cache never holds textures
+    cam = fs.meta["camera"]
+    assert abs(cam["fov"] - math.radians(90.0)) < 1e-6 and cam["clipping_near"] == float(np.float32(0.1))
+
+
+def test_monkey_scene_semantics():
+    fs = load_scene("monkey")
+    assert len(fs.items) == 1 and fs.items[0].id == 3 and len(fs.meshes[0].indices) == 15744
+    m = fs.materials[fs.items[0].material]
+    # .mtl values, then ambient = base * 0.01 (src/scene.rs:1284), then the JSON diff (refl .5, alpha .5, ior 1.5)
+    assert m.shininess == float(np.float32(323.999994)) and m.reflectivity == 0.5 and m.alpha == 0.5 and m.refraction_index == 1.5
+    assert abs(m.ambient_color[2] - 0.008) < 1e-6
+    t = fs.items[0].trans
+    assert abs(t[2, 3] + 10.0) < 1e-6 and abs(t[1, 1] - 1.3) < 1e-6                 # T * Ry(20 deg) * S(1.3)
+    assert abs(t[0, 0] - 1.3 * math.cos(math.radians(20))) < 1e-5 and abs(t[0, 2] - 1.3 * math.sin(math.radians(20))) < 1e-5
+    assert np.allclose(t.astype(np.float64) @ fs.items[0].trans_inv.astype(np.float64), np.eye(4), atol=1e-5)
+
+
+@needs_reference
+@pytest.mark.parametrize("name,path,w,h", [("spheres", "scene/spheres.json", 256, 256), ("monkey", "scene/monkey.json", 800, 600)])
+def test_loader_reproduces_committed_fixture(name, path, w, h):
+    from rustray_amd.scene import load_scene as load_ref
+    sc = load_ref(path, w, h, root=REF)
+    fs, g = sc.flatten(), load_scene(name)
+    assert len(fs.items) == len(g.items)
+    for a, b in zip(fs.items, g.items):
+        assert a.id == b.id and np.array_equal(a.trans, b.trans) and a.material == b.material
+    for a, b in zip(fs.materials, g.materials):
+        assert a == b
+    for a, b in zip(fs.meshes, g.meshes):
+        assert np.array_equal(a.positions, b.positions) and np.array_equal(a.indices, b.indices)
+
+
+@needs_reference
+def test_auto_camera_and_spot_light_for_kbert():
+    """kbert.json has no camera block: find_optimal_camera_pos runs (src/scene.rs:1426-1547)."""
+    fs = load_scene("kbert")
+    cam = Camera.from_state(fs.meta["camera"])
+    assert not cam.is_default_cam()
+    d = np.asarray(cam.dir) / np.linalg.norm(cam.dir)
+    assert np.allclose(d, -np.asarray([-0.5, 0.5, 1.0]) / np.linalg.norm([-0.5, 0.5, 1.0]), atol=1e-6)
+    assert fs.lights[0].light_type == 2 and abs(fs.lights[0].max_angle - math.radians(22.5)) < 1e-6
+    assert [m.smooth_shading for m in fs.materials[::2]] == [False, False]
+
+
+def test_camera_matrices():
+    c = Camera(); c.eye_pos = np.array([1.0, 2.0, 3.0]); c.dir = np.array([0.0, 0.0, -1.0]); c.init(200, 100)
+    assert np.allclose(c.projection @ c.projection_inverse, np.eye(4), atol=1e-9)
+    assert np.allclose(c.view @ c.view_inverse, np.eye(4), atol=1e-12)
+    # fov 90, aspect 2: x scale = 1 / (2 * tan 45)
+    assert abs(c.projection[0, 0] - 0.5) < 1e-7 and abs(c.projection[1, 1] - 1.0) < 1e-7
+    assert np.allclose(c.view_inverse[:3, 3], [1, 2, 3])
+    assert approx_equal(1.0, 1.0000001) and not approx_equal(1.0, 1.00001)
+
+
+def test_material_defaults_are_the_references():
+    m = Material()  # src/shape/mod.rs:138-180
+    assert (m.alpha, m.shininess, m.reflectivity, m.refraction_index, m.shadow_softness, m.roughness) == (1.0, 150.0, 0.0, 1.0, 0.01, 0.0)
+    assert m.specular_color == (0.8, 0.8, 0.8) and m.cast_shadow and m.receive_shadow and m.monte_carlo and m.smooth_shading
+    cfg = make_config()  # src/raytracing.rs:110-127
+    assert (cfg.samples, cfg.max_recursion, cfg.monte_carlo, cfg.gamma_correction) == (1, 6, 0, 0)
+    assert abs(cfg.fog_color[0] - 0.4) < 1e-7 and cfg.focal_length == 1.0 and cfg.aperture_size == 1.0
+
+
+@pytest.mark.parametrize("w,h,tw,th,n", [(1280, 720, 32, 8, 8), (100, 37, 32, 8, 3), (7, 5, 8, 8, 2), (64, 64, 8, 8, 1)])
+def test_region_pixels_partition(w, h, tw, th, n):
+    seen = np.zeros((h, w), np.int32)
+    for r in range(n):
+        xy = region_pixels(w, h, tw, th, n, r)
+        seen[xy[:, 1], xy[:, 0]] += 1
+    assert (seen == 1).all()
+    # first tile of rank 0 is row-major inside the tile
+    xy = region_pixels(w, h, tw, th, n, 0)
+    assert xy[0].tolist() == [0, 0] and xy[1].tolist() == ([1, 0] if min(tw, w) > 1 else [0, 1])
+
+
+def test_synthetic_scenes_are_deterministic_and_sized():
+    from rustray_amd import synthetic
+    a, b = synthetic.sponza_syn(grid=4), synthetic.sponza_syn(grid=4)
+    assert len(a.items) == len(b.items) and all(np.array_equal(x.trans, y.trans) for x, y in zip(a.items, b.items))
+    full = synthetic.sponza_syn()
+    assert len(full.items) > 50 and full.n_triangles_instanced() > 250000          # large BVH, top-level structure in use
+    h = synthetic.helmet_syn()
+    assert len(h.items) == 2 and 70000 < h.n_triangles_instanced() < 90000
+    m = h.materials[h.items[1].material]
+    assert m.texture[0] >= 0 and m.texture[3] >= 0 and m.texture[5] >= 0 and m.texture[6] >= 0
+    lo = synthetic.lotus_syn(grid=4)
+    assert lo.meta["config"]["aperture_size"] == 16.0 and lo.meta["config"]["focal_length"] == 20.0

@@ -1,0 +1,52 @@
+"""Accuracy of the oracle's pinned transcendentals against float64 (they stand in for Rust's f32::sin etc.)."""
+import ctypes as C
+
+import numpy as np
+
+
+def _ulp_err(got, want64):
+    want = want64.astype(np.float32)
+    ulp = np.spacing(np.abs(want)).astype(np.float64)
+    return np.abs(got.astype(np.float64) - want64) / np.maximum(ulp, 1e-45)
+
+
+def test_sincos_within_2ulp(oracle):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-np.pi, np.pi, 200000), rng.uniform(-50, 50, 50000), [0.0, np.pi / 4, -np.pi / 2]]).astype(np.float32)
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    oracle.lib().rro_sincos(x.ctypes.data_as(C.c_void_p), len(x), s.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p))
+    x64 = x.astype(np.float64)
+    # relative to ulp of the result, except near zeros of the function where absolute error matters
+    es = np.abs(s - np.sin(x64)); ec = np.abs(c - np.cos(x64))
+    assert es.max() < 2.5e-7 and ec.max() < 2.5e-7
+    big = np.abs(np.sin(x64)) > 0.1
+    assert _ulp_err(s[big], np.sin(x64[big])).max() <= 2.0
+    big = np.abs(np.cos(x64)) > 0.1
+    assert _ulp_err(c[big], np.cos(x64[big])).max() <= 2.0
+
+
+def test_acos_within_2ulp(oracle):
+    x = np.concatenate([np.random.default_rng(1).uniform(-1, 1, 200000), [-1.0, 1.0, 0.0, 0.5, -0.5]]).astype(np.float32)
+    y = np.zeros_like(x)
+    oracle.lib().rro_acos(x.ctypes.data_as(C.c_void_p), len(x), y.ctypes.data_as(C.c_void_p))
+    want = np.arccos(x.astype(np.float64))
+    ok = want > 1e-3
+    assert _ulp_err(y[ok], want[ok]).max() <= 2.5
+    assert np.abs(y - want).max() < 5e-7
+    z = np.asarray([1.5, -1.5, np.nan], np.float32); out = np.zeros_like(z)
+    oracle.lib().rro_acos(z.ctypes.data_as(C.c_void_p), 3, out.ctypes.data_as(C.c_void_p))
+    assert np.isnan(out).all()
+
+
+def test_atan2_within_2ulp_and_quadrants(oracle):
+    rng = np.random.default_rng(2)
+    yy = rng.uniform(-10, 10, 200000).astype(np.float32)
+    xx = rng.uniform(-10, 10, 200000).astype(np.float32)
+    out = np.zeros_like(xx)
+    oracle.lib().rro_atan2(yy.ctypes.data_as(C.c_void_p), xx.ctypes.data_as(C.c_void_p), len(xx), out.ctypes.data_as(C.c_void_p))
+    want = np.arctan2(yy.astype(np.float64), xx.astype(np.float64))
+    assert np.abs(out - want).max() < 6e-7
+    sp_y = np.asarray([0.0, 0.0, 1.0, -1.0, -0.0], np.float32); sp_x = np.asarray([1.0, -1.0, 0.0, 0.0, -1.0], np.float32)
+    o = np.zeros(5, np.float32)
+    oracle.lib().rro_atan2(sp_y.ctypes.data_as(C.c_void_p), sp_x.ctypes.data_as(C.c_void_p), 5, o.ctypes.data_as(C.c_void_p))
+    assert np.allclose(o, [0.0, np.pi, np.pi / 2, -np.pi / 2, -np.pi], atol=1e-7)
