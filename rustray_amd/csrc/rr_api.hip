@@ -94,6 +94,7 @@ struct rr_scene {
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
     hipEvent_t frame_a = nullptr, frame_b = nullptr;
+    uint32_t* h_count = nullptr; // pinned: level sizes read back between depth levels
 };
 
 static const uint32_t POOL_WORDS = 16384;
@@ -525,6 +526,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     HIP_TRY(s->counters.reserve(RR_CNT_WORDS * 8));
     HIP_TRY(hipEventCreate(&s->frame_a));
     HIP_TRY(hipEventCreate(&s->frame_b));
+    HIP_TRY(hipHostMalloc((void**)&s->h_count, 64, hipHostMallocDefault));
     const char* prof = getenv("RR_PROFILE");
     s->profiling = prof && atoi(prof) != 0;
     *out = s.release();
@@ -544,6 +546,7 @@ extern "C" void rr_scene_destroy(rr_scene* s) {
     for (auto& t : s->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     if (s->frame_a) (void)hipEventDestroy(s->frame_a);
     if (s->frame_b) (void)hipEventDestroy(s->frame_b);
+    if (s->h_count) (void)hipHostFree(s->h_count);
     delete s;
 }
 
@@ -673,8 +676,17 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     const uint32_t R = cfg->max_recursion;
     uint64_t f_odd = 1, f_even = 0;
     for (uint32_t d = 1; d <= R + 1; d++) { uint64_t f = 1ull << (d - 1); if (d & 1) f_odd = std::max(f_odd, f); else f_even = std::max(f_even, f); }
+    // Queue memory: a quarter of what is free on the device, at most 64 GB (MI355X has 288 GB of HBM3E),
+    // unless RR_QUEUE_BUDGET_MB says otherwise.  Memory already held by this scene's queues counts as free.
     const char* env_budget = getenv("RR_QUEUE_BUDGET_MB");
-    uint64_t budget = (env_budget ? (uint64_t)atoll(env_budget) : 16384ull) << 20;
+    uint64_t budget;
+    if (env_budget) budget = (uint64_t)atoll(env_budget) << 20;
+    else {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        uint64_t held = 56ull * (s->q_cap[0] + s->q_cap[1]);
+        budget = std::min<uint64_t>((free_b + held) / 4, 64ull << 30);
+    }
     const uint64_t total_primary = (uint64_t)npix * cfg->samples;
     uint64_t B = budget / (56ull * (f_odd + f_even));
     B = std::max<uint64_t>(B, 4096);
@@ -716,16 +728,19 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         // The batch covers primary indices [first, first + n_batch): index i -> sample i / npix, pixel i % npix.
         hipLaunchKernelGGL(k_raygen, dim3((n_batch + RR_BLOCK - 1) / RR_BLOCK), dim3(RR_BLOCK), 0, st, fr, s->region_xy.as<uint32_t>(),
                            s->sample_xy.as<uint16_t>(), (unsigned long long)first, n_batch, Q[0], &level_count[1], counters);
-        uint64_t ub = n_batch; // upper bound of the level size
-        for (uint32_t d = 1; d <= R + 1; d++) {
+        // Depth levels.  The size of the next level is read back once per level (one 4-byte copy + stream
+        // sync): launches are then sized by the rays that exist, and empty levels are never launched.
+        uint64_t n_level = n_batch;
+        for (uint32_t d = 1; d <= R + 1 && n_level > 0; d++) {
             const DRayQueue& qin = Q[(d - 1) & 1];
             const DRayQueue& qout = Q[d & 1];
             {
                 ScopedTimer t(s, st, 0);
-                hipLaunchKernelGGL(k_trace_closest, dim3(trace_grid), dim3(RR_BLOCK), 0, st, s->view, qin, &level_count[d], word());
+                const int grid = (int)std::min<uint64_t>((n_level + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)trace_grid);
+                hipLaunchKernelGGL(k_trace_closest, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, qin, &level_count[d], word());
             }
-            for (uint64_t c0 = 0; c0 < ub; c0 += chunk) {
-                const uint64_t c1 = std::min<uint64_t>(c0 + chunk, ub);
+            for (uint64_t c0 = 0; c0 < n_level; c0 += chunk) {
+                const uint64_t c1 = std::min<uint64_t>(c0 + chunk, n_level);
                 if (next_word + 3 >= POOL_WORDS) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise RR_SHADE_CHUNK");
                 uint32_t* sq_count = word();
                 const int grid = (int)std::min<uint64_t>((c1 - c0 + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)shade_grid_max);
@@ -736,10 +751,16 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
                 }
                 if (s->n_enabled_lights) {
                     ScopedTimer t(s, st, 1);
-                    hipLaunchKernelGGL(k_trace_shadow, dim3(trace_grid), dim3(RR_BLOCK), 0, st, s->view, SQ, sq_count, word(), acc);
+                    const uint64_t sq_ub = (c1 - c0) * s->n_enabled_lights;
+                    const int sgrid = (int)std::min<uint64_t>((sq_ub + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)trace_grid);
+                    hipLaunchKernelGGL(k_trace_shadow, dim3(sgrid), dim3(RR_BLOCK), 0, st, s->view, SQ, sq_count, word(), acc);
                 }
             }
-            ub = std::min<uint64_t>(ub * 2, cap[d & 1]);
+            if (d == R + 1) break; // the deepest level spawns nothing
+            HIP_TRY(hipMemcpyAsync(s->h_count, &level_count[d + 1], 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            n_level = *s->h_count;
+            if (n_level > cap[d & 1]) return fail(RR_ERR_DEVICE, "internal: level %u holds %llu rays, capacity %llu", d + 1, (unsigned long long)n_level, (unsigned long long)cap[d & 1]);
         }
         HIP_TRY(hipGetLastError());
         // batches are stream-ordered; only a caller that can cancel needs the host to keep pace with the device
