@@ -632,6 +632,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         s->region_cached = *rg; s->region_w = W; s->region_h = H;
     }
     const uint32_t npix = (uint32_t)s->h_region_xy.size();
+    resolve_timers(s); // launches of an earlier frame nobody asked about must not leak into this frame's stats
     memset(&s->stats, 0, sizeof s->stats);
     if (npix == 0) return RR_OK;
 
@@ -670,6 +671,10 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     HIP_TRY(hipMemsetAsync(s->acc_id.p, 0, (size_t)npix * 4, st));
     HIP_TRY(hipMemsetAsync(s->counters.p, 0, RR_CNT_WORDS * 8, st));
     DAccum acc{s->acc_rgb.as<long long>(), s->acc_normal.as<long long>(), s->acc_depth.as<long long>(), s->acc_id.as<uint32_t>()};
+    // aux outputs the caller did not ask for are not accumulated at all
+    if (!out->normal) acc.normal = nullptr;
+    if (!out->depth) acc.depth = nullptr;
+    if (!out->object_id) acc.object_id = nullptr;
 
     // ---- batch sizing.  Level d (1-based depth) holds at most B * 2^(d-1) rays, d <= max_recursion + 1;
     // odd levels live in queue 0, even levels in queue 1.

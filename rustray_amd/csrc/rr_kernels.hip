@@ -722,11 +722,13 @@ __global__ __launch_bounds__(RR_BLOCK) void k_shade(DSceneView sc, DFrame fr, co
         }
         // ---- aux outputs of the root node (:742-744, :400-402)
         if (depth == 1u) {
-            atomicAdd((unsigned long long*)(acc.depth + pix), (unsigned long long)to_fix(hit_dist, RR_DEPTH_SCALE, 1.0e9f));
-            unsigned long long* np = (unsigned long long*)(acc.normal + 3ull * pix);
-            atomicAdd(np + 0, (unsigned long long)to_fix(normal.x, RR_FIX_SCALE, RR_FIX_CLAMP));
-            atomicAdd(np + 1, (unsigned long long)to_fix(normal.y, RR_FIX_SCALE, RR_FIX_CLAMP));
-            atomicAdd(np + 2, (unsigned long long)to_fix(normal.z, RR_FIX_SCALE, RR_FIX_CLAMP));
+            if (acc.depth) atomicAdd((unsigned long long*)(acc.depth + pix), (unsigned long long)to_fix(hit_dist, RR_DEPTH_SCALE, 1.0e9f));
+            if (acc.normal) {
+                unsigned long long* np = (unsigned long long*)(acc.normal + 3ull * pix);
+                atomicAdd(np + 0, (unsigned long long)to_fix(normal.x, RR_FIX_SCALE, RR_FIX_CLAMP));
+                atomicAdd(np + 1, (unsigned long long)to_fix(normal.y, RR_FIX_SCALE, RR_FIX_CLAMP));
+                atomicAdd(np + 2, (unsigned long long)to_fix(normal.z, RR_FIX_SCALE, RR_FIX_CLAMP));
+            }
         }
         // ---- uv (:749-754)
         bool has_uv = false; f2 uv; uv.x = 0.0f; uv.y = 0.0f;
@@ -815,7 +817,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_shade(DSceneView sc, DFrame fr, co
         }
         // ---- object id (:744, :966-969): the last sample's id, passed through fully transparent hits
         const bool child_idc = idc && spawn_refr && approx_equal(alpha, 0.0f);
-        if (idc && !child_idc && sample + 1u == fr.samples) acc.object_id[pix] = it.id;
+        if (acc.object_id && idc && !child_idc && sample + 1u == fr.samples) acc.object_id[pix] = it.id;
 
         // ---- lights (:814-920)
         const f3 view_dir = normalize3(-rd);
@@ -968,14 +970,14 @@ __global__ __launch_bounds__(RR_BLOCK) void k_resolve(DFrame fr, const uint32_t*
         r = as_u8(c[0] * 255.0f); g = as_u8(c[1] * 255.0f); b = as_u8(c[2] * 255.0f);
     }
     ((uint32_t*)rgba8)[o] = r | (g << 8) | (b << 16) | (255u << 24);
-    if (normal) {
+    if (normal && acc.normal) {
         f3 nn = mk3((float)((double)acc.normal[3ull * p] * inv_fix) / n, (float)((double)acc.normal[3ull * p + 1] * inv_fix) / n,
                     (float)((double)acc.normal[3ull * p + 2] * inv_fix) / n);
         nn = normalize3(nn); // 0/0 = NaN on all-miss pixels, as in the reference (:426)
         normal[3ull * o] = nn.x; normal[3ull * o + 1] = nn.y; normal[3ull * o + 2] = nn.z;
     }
-    if (depth) depth[o] = (float)((double)acc.depth[p] * (1.0 / 65536.0)) / n;
-    if (object_id) object_id[o] = acc.object_id[p];
+    if (depth && acc.depth) depth[o] = (float)((double)acc.depth[p] * (1.0 / 65536.0)) / n;
+    if (object_id && acc.object_id) object_id[o] = acc.object_id[p];
 }
 
 // ---------------------------------------------------------------------------
