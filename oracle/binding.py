@@ -42,6 +42,10 @@ def lib():
     if _LIB is None:
         _LIB = C.CDLL(build())
         _LIB.rro_render.restype = C.c_int
+        _LIB.rro_render_scene.restype = C.c_int
+        _LIB.rro_scene_create.restype = C.c_void_p
+        _LIB.rro_scene_destroy.argtypes = [C.c_void_p]
+        _LIB.rro_render_scene.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]
         _LIB.rro_wrap.restype = C.c_uint32
         _LIB.rro_wrap.argtypes = [C.c_float, C.c_uint32]
         _LIB.rro_fresnel.restype = C.c_float
@@ -68,9 +72,27 @@ def sample_table(samples: int):
     return xy[:samples], int(cs.value)
 
 
-def render(fs_struct: rr_flat_scene, cam: rr_camera, cfg: rr_config, sample_xy=None, window=None,
+class PreparedScene:
+    """Acceleration structures built once; `fs_struct` must outlive the handle."""
+
+    def __init__(self, fs_struct: rr_flat_scene, brute_force: bool = False):
+        lib().rro_scene_create.restype = C.c_void_p
+        self._fs = fs_struct
+        self._h = C.c_void_p(lib().rro_scene_create(C.byref(fs_struct), 1 if brute_force else 0))
+
+    def close(self):
+        if self._h:
+            lib().rro_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def render(fs_struct, cam: rr_camera, cfg: rr_config, sample_xy=None, window=None,
            n_threads: int = 1, brute_force: bool = False, want_counters: bool = False):
-    """Render with the CPU restatement.  Returns dict(rgba, normal, depth, object_id[, counters])."""
+    """Render with the CPU restatement.  `fs_struct`: an rr_flat_scene or a PreparedScene.
+    Returns dict(rgba, normal, depth, object_id[, counters])."""
     w, h = cam.width, cam.height
     rgba = np.zeros((h, w, 4), np.uint8)
     normal = np.zeros((h, w, 3), np.float32)
@@ -83,9 +105,14 @@ def render(fs_struct: rr_flat_scene, cam: rr_camera, cfg: rr_config, sample_xy=N
     if sample_xy is not None:
         sample_xy = np.ascontiguousarray(sample_xy, np.uint16)
         sxy = _p(sample_xy)
-    rc = lib().rro_render(C.byref(fs_struct), C.byref(cam), C.byref(cfg), sxy, C.byref(fr),
-                          C.c_int(x0), C.c_int(y0), C.c_int(x1), C.c_int(y1), C.c_int(n_threads),
-                          C.c_int(1 if brute_force else 0), C.byref(cnt) if want_counters else None)
+    if isinstance(fs_struct, PreparedScene):
+        rc = lib().rro_render_scene(fs_struct._h, C.byref(cam), C.byref(cfg), sxy, C.byref(fr),
+                                    C.c_int(x0), C.c_int(y0), C.c_int(x1), C.c_int(y1), C.c_int(n_threads),
+                                    C.byref(cnt) if want_counters else None)
+    else:
+        rc = lib().rro_render(C.byref(fs_struct), C.byref(cam), C.byref(cfg), sxy, C.byref(fr),
+                              C.c_int(x0), C.c_int(y0), C.c_int(x1), C.c_int(y1), C.c_int(n_threads),
+                              C.c_int(1 if brute_force else 0), C.byref(cnt) if want_counters else None)
     if rc != 0:
         raise RuntimeError(f"rro_render failed: {rc}")
     out = dict(rgba=rgba, normal=normal, depth=depth, object_id=oid)

@@ -1216,6 +1216,27 @@ int rro_sample_table(uint16_t samples, uint16_t* xy_out, uint32_t* cell_size_out
 // Render the window [x0,x1) x [y0,y1) of the frame with n_threads worker threads
 // pulling shuffled 2x2 cells (mirrors reference src/renderer.rs:17, :125-172).
 // Outputs are full-frame buffers (only the window is written).
+// A prepared scene: acceleration structures built once (their build time is not part of a frame,
+// like Scene::update in the reference, src/scene.rs:1674-1688).
+void* rro_scene_create(const rr_flat_scene* fs, int brute_force) {
+    if (!fs) return nullptr;
+    OScene* sc = new OScene;
+    sc->fs = fs; // borrowed: the caller keeps the flat scene alive
+    sc->brute_force = brute_force != 0;
+    sc->prepare();
+    return sc;
+}
+void rro_scene_destroy(void* h) { delete (OScene*)h; }
+
+static int render_prepared(const OScene& sc, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy, const rr_frame* out,
+                           int x0, int y0, int x1, int y1, int n_threads, rro_counters* counters);
+
+int rro_render_scene(void* h, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy, const rr_frame* out,
+                     int x0, int y0, int x1, int y1, int n_threads, rro_counters* counters) {
+    if (!h || !cam || !cfg || !out || !out->rgba8) return -1;
+    return render_prepared(*(OScene*)h, cam, cfg, sample_xy, out, x0, y0, x1, y1, n_threads, counters);
+}
+
 int rro_render(const rr_flat_scene* fs, const rr_camera* cam, const rr_config* cfg,
                const uint16_t* sample_xy, const rr_frame* out,
                int x0, int y0, int x1, int y1, int n_threads, int brute_force, rro_counters* counters) {
@@ -1224,6 +1245,13 @@ int rro_render(const rr_flat_scene* fs, const rr_camera* cam, const rr_config* c
     sc.fs = fs;
     sc.brute_force = brute_force != 0;
     sc.prepare();
+    return render_prepared(sc, cam, cfg, sample_xy, out, x0, y0, x1, y1, n_threads, counters);
+}
+
+static int render_prepared(const OScene& sc, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy, const rr_frame* out,
+                           int x0, int y0, int x1, int y1, int n_threads, rro_counters* counters) {
+    const rr_flat_scene* fs = sc.fs;
+    (void)fs;
     std::vector<uint16_t> table;
     uint32_t cell_size = cell_size_for(cfg->samples);
     if (!sample_xy) {

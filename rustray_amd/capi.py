@@ -15,7 +15,7 @@ import numpy as np
 from .flat import (rr_camera, rr_config, rr_flat_scene, rr_frame, rr_frame_stats, rr_pick_result, rr_region)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librustray_hip.so")
+LIB_PATH = os.environ.get("RUSTRAY_HIP_LIB") or os.path.join(_HERE, "librustray_hip.so")  # override: developer A/B builds
 _LIB = None
 
 EXPORTS = ["rr_device_count", "rr_last_error", "rr_scene_create", "rr_scene_destroy", "rr_scene_update_transforms",

@@ -486,17 +486,16 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         d.flags = f;
     }
 
-    // ---- top level
+    // ---- top level: always present (even for one item), so the kernels have a single traversal path.
+    // The reference's choice between "all items" and its scene BVH (src/raytracing.rs:434) only changes the
+    // candidate set, never the result.
     std::vector<DNode> tlas;
-    int32_t tlas_root = 0;
-    uint32_t use_tlas = 0;
-    const char* env_tlas = getenv("RR_TLAS_MIN_ITEMS");
-    uint32_t tlas_min = env_tlas ? (uint32_t)atoi(env_tlas) : 9u;
-    if (fs->n_items >= tlas_min && fs->n_items >= 2) {
+    int32_t tlas_root = (int32_t)0x80000000; // RR_SENTINEL: empty scene
+    uint32_t use_tlas = 1;
+    if (fs->n_items >= 1) {
         std::vector<rr_item> items(fs->items, fs->items + fs->n_items);
         rc = build_tlas(s.get(), items, &tlas, &tlas_root);
         if (rc != RR_OK) return rc;
-        use_tlas = 1;
     }
     uint32_t tlas_base = (uint32_t)all_nodes.size();
     s->tlas_node_capacity = std::max<uint32_t>((uint32_t)tlas.size(), fs->n_items ? fs->n_items : 1u);

@@ -146,8 +146,18 @@ RR_DEV bool ray_ball(float radius, const LRay& ray, bool solid, float* toi_out, 
 // BVH2 traversal.  Per-lane stack in LDS, lane-interleaved (conflict free).
 // ---------------------------------------------------------------------------
 #define STK(sp) s_stack[(sp) * RR_BLOCK + threadIdx.x]
+#define RR_SENTINEL ((int)0x80000000) // top-level root of an empty scene
 
+// The traversal's own box test is NOT part of the parity contract (only the exact primitive tests decide
+// hits), so its reciprocal is the hardware approximation.  The subtraction stays in front of the multiply:
+// the fused form plane * inv - o * inv cancels catastrophically when the origin sits within the shadow bias
+// of a box plane (measured as missed hits on scenes/spheres_room).
 struct SlabRay { f3 o, inv; };
+RR_DEV SlabRay make_slab(f3 o, f3 d) {
+    SlabRay r; r.o = o;
+    r.inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    return r;
+}
 
 // Conservative slab test against a (builder-padded) box.  The relative slack
 // on both ends widens the box in proportion to its distance from the origin,
@@ -159,9 +169,9 @@ RR_DEV bool slab2(float lox, float hix, float loy, float hiy, float loz, float h
     float az = (loz - r.o.z) * r.inv.z, bz = (hiz - r.o.z) * r.inv.z;
     float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
     float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), RR_FLT_MAX));
-    float tn_c = tn * 0.999998f;
+    float tn_c = tn * 0.999996f;
     *entry = tn;
-    return tn_c <= tf * 1.000002f && tn_c <= bound;
+    return tn_c <= tf * 1.000004f && tn_c <= bound;
 }
 
 // Nearest triangle of one mesh (TriMesh::cast_local_ray_and_get_normal,
@@ -173,7 +183,7 @@ struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool foun
 RR_DEV void blas_closest(const DSceneView& sc, const DItem& it, const LRay& ray, float gbound,
                          int* s_stack, int sp_base, TriBest* out) {
     TriBest best; best.found = false; best.t = RR_FLT_MAX; best.slot = 0; best.face = 0xffffffffu; best.side = 0u;
-    SlabRay sr; sr.o = ray.o; sr.inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    const SlabRay sr = make_slab(ray.o, ray.d);
     const DNode* nodes = sc.nodes + it.node_base;
     const DTri* tris = sc.tris + it.tri_base;
     int sp = sp_base;
@@ -223,7 +233,7 @@ RR_DEV void blas_closest(const DSceneView& sc, const DItem& it, const LRay& ray,
 RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, float limit,
                      int* s_stack, int sp_base, bool* found_any, bool* found_within) {
     bool any = false, within = false;
-    SlabRay sr; sr.o = ray.o; sr.inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    const SlabRay sr = make_slab(ray.o, ray.d);
     const DNode* nodes = sc.nodes + it.node_base;
     const DTri* tris = sc.tris + it.tri_base;
     int sp = sp_base;
@@ -271,6 +281,32 @@ RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, flo
 // ---------------------------------------------------------------------------
 // Raytracing::trace (reference src/raytracing.rs:429-490) per item
 // ---------------------------------------------------------------------------
+// Aabb::cast_local_ray with the entry distance kept beside the returned toi: origin inside a
+// non-solid box returns the EXIT distance as toi (the sort key) although hits may be nearer.
+RR_DEV bool aabb_cast2(const float* mins, const float* maxs, const LRay& ray, bool solid, float* toi, float* tmin_out) {
+    float tmin = 0.0f, tmax = RR_FLT_MAX;
+    const float o[3] = {ray.o.x, ray.o.y, ray.o.z};
+    const float d[3] = {ray.d.x, ray.d.y, ray.d.z};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (d[i] == 0.0f) {
+            if (o[i] < mins[i] || o[i] > maxs[i]) return false;
+        } else {
+            float denom = 1.0f / d[i];
+            float a = (mins[i] - o[i]) * denom;
+            float b = (maxs[i] - o[i]) * denom;
+            float inear = (a > b) ? b : a;
+            float ifar = (a > b) ? a : b;
+            tmin = rs_max(tmin, inear);
+            tmax = rs_min(tmax, ifar);
+            if (tmin > tmax) return false;
+        }
+    }
+    *toi = (tmin == 0.0f && !solid) ? tmax : tmin;
+    *tmin_out = tmin;
+    return true;
+}
+
 // candidate filter of :454 on the texture-less material cache
 RR_DEV bool item_passes(uint32_t flags, bool for_shadow, uint32_t depth) {
     if (!(flags & RR_IF_VISIBLE)) return false;
@@ -314,16 +350,13 @@ RR_DEV void closest_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t dep
 
 RR_DEV void trace_closest_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, int* s_stack, Closest* best) {
     best->found = false; best->t = RR_FLT_MAX; best->item = -1; best->face = 0u; best->key = 0.0f;
-    if (!sc.use_tlas) {
-        for (uint32_t i = 0; i < sc.n_items; i++) closest_item(sc, (int)i, o, d, depth, s_stack, 0, best);
-        return;
-    }
     // top level: world-space boxes over items (stands in for Scene::get_possible_hits_by_ray,
     // reference src/scene.rs:1715-1722; any conservative candidate set gives the same result)
-    SlabRay sr; sr.o = o; sr.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const SlabRay sr = make_slab(o, d);
     const DNode* nodes = sc.nodes + sc.tlas_node_base;
     int sp = 0;
     int cur = sc.tlas_root;
+    if (cur == RR_SENTINEL) return; // empty scene
     for (;;) {
         if (cur >= 0) {
             const DNode nd = nodes[cur];
@@ -359,9 +392,11 @@ RR_DEV void shadow_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t dept
     uint32_t flags = it.flags;
     if (!item_passes(flags, true, depth)) return;
     LRay lr = inverse_ray(it, o, d, sc.general_w != 0u);
-    float key;
-    if (!aabb_cast(it.bmin, it.bmax, lr, false, &key)) return; // for_shadow forces solid = false
+    float key, tmin;
+    if (!aabb_cast2(it.bmin, it.bmax, lr, false, &key, &tmin)) return; // for_shadow forces solid = false
     if (key != key) return;
+    // An item whose box starts beyond the light cannot change the outcome: selected or not, the receiver is lit.
+    if (tmin > limit) return;
     if (sel->found && !(key < sel->key || (key == sel->key && idx < sel->item))) return;
     bool any = false, within = false; float t = 0.0f; uint32_t face = 0u;
     if (flags & RR_IF_SPHERE) {
@@ -381,19 +416,16 @@ RR_DEV void shadow_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t dept
 
 RR_DEV void trace_shadow_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, float limit, int* s_stack, ShadowSel* sel) {
     sel->found = false; sel->within = false; sel->key = 0.0f; sel->item = -1; sel->t = 0.0f; sel->face = 0u;
-    if (!sc.use_tlas) {
-        for (uint32_t i = 0; i < sc.n_items; i++) shadow_item(sc, (int)i, o, d, depth, limit, s_stack, 0, sel);
-        return;
-    }
-    SlabRay sr; sr.o = o; sr.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const SlabRay sr = make_slab(o, d);
     const DNode* nodes = sc.nodes + sc.tlas_node_base;
     int sp = 0;
     int cur = sc.tlas_root;
+    if (cur == RR_SENTINEL) return; // empty scene
     for (;;) {
         if (cur >= 0) {
             const DNode nd = nodes[cur];
-            // an item whose world box starts beyond the selected item's key cannot precede it
-            float bound = sel->found ? sel->key * 1.00001f + 1e-6f : RR_FLT_MAX;
+            // an item whose world box starts beyond the light, or beyond the selected item's key, cannot matter
+            float bound = sel->found ? fminf(limit, sel->key * 1.00001f + 1e-6f) : limit;
             float e0, e1;
             bool h0 = slab2(nd.n0.x, nd.n0.y, nd.n0.z, nd.n0.w, nd.n2.x, nd.n2.y, sr, bound, &e0);
             bool h1 = slab2(nd.n1.x, nd.n1.y, nd.n1.z, nd.n1.w, nd.n2.z, nd.n2.w, sr, bound, &e1);
@@ -921,8 +953,9 @@ __global__ __launch_bounds__(RR_BLOCK) void k_trace_shadow(DSceneView sc, DShado
             const f3 o = mk3(s0.x, s0.y, s0.z), d = mk3(s1.x, s1.y, s1.z);
             ShadowSel sel;
             trace_shadow_ray(sc, o, d, s3.y, s0.w, s_stack, &sel);
+            const bool occluded = sel.found && sel.within;
             float factor = 1.0f;
-            if (sel.found && sel.within) {
+            if (occluded) {
                 float shadow_source_alpha = s1.w; // the RECEIVER's material.alpha (:898)
                 const DItem& occ = sc.items[sel.item];
                 if (occ.flags & RR_IF_OCCLUDER_ALPHA_TEX) {
