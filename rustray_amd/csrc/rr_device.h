@@ -20,7 +20,9 @@ struct DNode { float4 n0, n1, n2, n3; };
 #define RR_MAX_LEAF_TRIS 4
 #define RR_BLAS_MAX_DEPTH 26
 #define RR_TLAS_MAX_DEPTH 12
+#ifndef RR_STACK_DEPTH
 #define RR_STACK_DEPTH (RR_BLAS_MAX_DEPTH + RR_TLAS_MAX_DEPTH + 2)
+#endif
 
 // Triangle for intersection, 48 B (3 x dwordx4), in BVH leaf order:
 //   v0 = (a.xyz, bits(original face index)), v1 = (b.xyz, 0), v2 = (c.xyz, 0)

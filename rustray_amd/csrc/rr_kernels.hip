@@ -24,6 +24,9 @@
 #include "rr_math.h"
 
 #define RR_BLOCK 256
+#ifndef RR_TRACE_WAVES
+#define RR_TRACE_WAVES 4 // waves per SIMD the trace kernels are built for (bounds VGPRs; LDS stack: RR_STACK_DEPTH KB per workgroup)
+#endif
 #define RR_WAVE 64
 
 __constant__ float c_u8_to_f32[256]; // i / 255.0f, exactly as `(p[0] as f32) / 255.0`
@@ -592,6 +595,7 @@ RR_DEV float4 mat4_mul(const float* m, float x, float y, float z, float w) {
 }
 
 __global__ __launch_bounds__(RR_BLOCK) void k_raygen(DFrame fr, const uint32_t* __restrict__ region_xy,
+                                                     const uint32_t* __restrict__ trace_order,
                                                      const uint16_t* __restrict__ sample_xy,
                                                      unsigned long long first, uint32_t n_rays, DRayQueue q,
                                                      uint32_t* q_count, unsigned long long* counters) {
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_raygen(DFrame fr, const uint32_t* 
     if (i == 0) { *q_count = n_rays; atomicAdd(&counters[RR_CNT_PRIMARY], (unsigned long long)n_rays); }
     if (i >= n_rays) return;
     const unsigned long long gi = first + i; // sample-major index over the region: sample = gi / n_pix
-    uint32_t pix = (uint32_t)(gi % fr.n_region_pixels);
+    uint32_t pix = trace_order[(uint32_t)(gi % fr.n_region_pixels)]; // 8x8 blocks of the region's tiles
     uint32_t s = (uint32_t)(gi / fr.n_region_pixels);
     uint32_t xy = region_xy[pix];
     float x_f = (float)(xy & 0xffffu), y_f = (float)(xy >> 16);
@@ -650,7 +654,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_raygen(DFrame fr, const uint32_t* 
 // ---------------------------------------------------------------------------
 // kernel 2: closest hit for a queue of rays
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(RR_BLOCK) void k_trace_closest(DSceneView sc, DRayQueue q, const uint32_t* __restrict__ q_count,
+__global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_closest(DSceneView sc, DRayQueue q, const uint32_t* __restrict__ q_count,
                                                             uint32_t* head) {
     __shared__ int s_stack[RR_STACK_DEPTH * RR_BLOCK];
     const uint32_t n = *q_count;
@@ -938,7 +942,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_shade(DSceneView sc, DFrame fr, co
 // ---------------------------------------------------------------------------
 // kernel 4: shadow rays of one shade chunk (reference src/raytracing.rs:872-914)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(RR_BLOCK) void k_trace_shadow(DSceneView sc, DShadowQueue sq, const uint32_t* __restrict__ sq_count,
+__global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DSceneView sc, DShadowQueue sq, const uint32_t* __restrict__ sq_count,
                                                            uint32_t* head, DAccum acc) {
     __shared__ int s_stack[RR_STACK_DEPTH * RR_BLOCK];
     const uint32_t n = *sq_count;
