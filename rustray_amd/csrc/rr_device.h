@@ -18,10 +18,13 @@ struct DNode { float4 n0, n1, n2, n3; };
 #define RR_LEAF_FIRST(code) ((uint32_t)(code) & 0x0fffffffu)
 #define RR_LEAF_COUNT(code) ((((uint32_t)(code)) >> 28) + 1u)
 #define RR_MAX_LEAF_TRIS 4
-#define RR_BLAS_MAX_DEPTH 26
+// Depth limits enforced by the host builder, so the fixed LDS stack can never overflow: per level one
+// sentinel entry plus at most one pending sibling per inner node on the path, plus one scratch slot above the
+// top (the node step writes the far child before it knows whether it is needed).
+#define RR_BLAS_MAX_DEPTH 25
 #define RR_TLAS_MAX_DEPTH 12
 #ifndef RR_STACK_DEPTH
-#define RR_STACK_DEPTH (RR_BLAS_MAX_DEPTH + RR_TLAS_MAX_DEPTH + 2)
+#define RR_STACK_DEPTH (RR_BLAS_MAX_DEPTH + RR_TLAS_MAX_DEPTH + 3)
 #endif
 
 // Triangle for intersection, 48 B (3 x dwordx4), in BVH leaf order:

@@ -1,7 +1,8 @@
 #!/bin/bash
-# A/B developer bench: runs bench.py against several builds of the library (RUSTRAY_HIP_LIB) on one box.
+# A/B developer bench on ONE box: ab.sh "<bench args>" lib1 lib2 ...   (boxes differ by several %, never compare across calls)
+args=$1; shift
 for lib in "$@"; do
-  echo "== $lib"
-  RUSTRAY_HIP_LIB=$PWD/$lib python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
+  echo "== $lib $args"
+  RUSTRAY_HIP_LIB=$PWD/$lib python bench.py --steps 3 --warmup 1 --no-cpu-baseline $args 2>/dev/null | python -c "
 import json,sys; r=json.loads(sys.stdin.read()); print(round(r['value']), round(r['ms_per_step'],2), {k: round(v,2) for k,v in r['kernel_ms_per_frame'].items()}, r['frame_checksum'])"
 done
