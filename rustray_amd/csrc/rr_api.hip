@@ -83,7 +83,7 @@ struct rr_scene {
     DevBuf sq[4];
     size_t sq_cap = 0;
     DevBuf acc_rgb, acc_normal, acc_depth, acc_id;
-    DevBuf region_xy, trace_order, sample_xy, pool, counters;
+    DevBuf region_xy, trace_order, sample_xy, pool, counters; // region_xy: pixel of each accumulator slot; trace_order: its output index
     DevBuf tmp_out[4];
     std::vector<uint32_t> h_region_xy;
     rr_region region_cached{0, 0, 0, 0};
@@ -189,9 +189,10 @@ extern "C" int rr_device_count(void) {
 extern "C" const char* rr_last_error(void) { return tl_error.c_str(); }
 
 // xy: the region's pixels in OUTPUT order (tile order, row-major inside the tile; the ABI contract).
-// trace_order (optional): a permutation of region indices in which primary rays are generated: 8x8-pixel
-// blocks inside each tile, so that the 64 lanes of a wave start as one compact bundle of rays whatever the
-// tile shape is (32x8 tiles traced in row-major order cost 4 % more than 8x8 blocks on sponza_syn).
+// trace_order (optional): a permutation of region indices = the order of the ACCUMULATOR SLOTS, in which
+// primary rays are generated: 8x8-pixel blocks inside each tile, so that the 64 lanes of a wave start as one
+// compact bundle of rays whatever the tile shape is (32x8 tiles traced in row-major order cost 4 % more than
+// 8x8 blocks on sponza_syn) and add to 64 consecutive accumulator words.
 static void fill_region(uint32_t w, uint32_t h, const rr_region& rg, std::vector<uint32_t>* xy, std::vector<uint32_t>* trace_order = nullptr) {
     xy->clear();
     if (trace_order) trace_order->clear();
@@ -641,7 +642,10 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         HIP_TRY(s->region_xy.reserve(std::max<size_t>(s->h_region_xy.size(), 1) * 4));
         HIP_TRY(s->trace_order.reserve(std::max<size_t>(order.size(), 1) * 4));
         if (!s->h_region_xy.empty()) {
-            HIP_TRY(hipMemcpy(s->region_xy.p, s->h_region_xy.data(), s->h_region_xy.size() * 4, hipMemcpyHostToDevice));
+            // slot_xy[j] = pixel of accumulator slot j; slot_out[j] = its index in the compact output order
+            std::vector<uint32_t> slot_xy(order.size());
+            for (size_t j = 0; j < order.size(); j++) slot_xy[j] = s->h_region_xy[order[j]];
+            HIP_TRY(hipMemcpy(s->region_xy.p, slot_xy.data(), slot_xy.size() * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(s->trace_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice));
         }
         s->region_cached = *rg; s->region_w = W; s->region_h = H;
@@ -685,7 +689,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     HIP_TRY(hipMemsetAsync(s->acc_depth.p, 0, (size_t)npix * 8, st));
     HIP_TRY(hipMemsetAsync(s->acc_id.p, 0, (size_t)npix * 4, st));
     HIP_TRY(hipMemsetAsync(s->counters.p, 0, RR_CNT_WORDS * 8, st));
-    DAccum acc{s->acc_rgb.as<long long>(), s->acc_normal.as<long long>(), s->acc_depth.as<long long>(), s->acc_id.as<uint32_t>()};
+    DAccum acc{s->acc_rgb.as<long long>(), s->acc_normal.as<long long>(), s->acc_depth.as<long long>(), s->acc_id.as<uint32_t>(), (unsigned long long)npix};
     // aux outputs the caller did not ask for are not accumulated at all
     if (!out->normal) acc.normal = nullptr;
     if (!out->depth) acc.depth = nullptr;
@@ -722,7 +726,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         }
     const char* env_chunk = getenv("RR_SHADE_CHUNK");
     const uint64_t chunk = env_chunk ? std::max<uint64_t>(65536, (uint64_t)atoll(env_chunk)) : (4ull << 20);
-    const uint64_t sq_need = std::max<uint64_t>(1, std::min<uint64_t>(chunk, cap[0]) * std::max<uint32_t>(s->n_enabled_lights, 1u));
+    const uint64_t sq_need = std::max<uint64_t>(1, (std::min<uint64_t>(chunk, cap[0]) + RR_BLOCK * RR_SQ_SHARDS) * std::max<uint32_t>(s->n_enabled_lights, 1u));
     if (sq_need > s->sq_cap) {
         for (int k = 0; k < 4; k++) HIP_TRY(s->sq[k].reserve(sq_need * 16));
         s->sq_cap = sq_need;
@@ -734,7 +738,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     uint32_t* pool = s->pool.as<uint32_t>();
     unsigned long long* counters = s->counters.as<unsigned long long>();
     const int trace_grid = s->n_cus * RR_TRACE_WAVES; // RR_STACK_DEPTH KB of LDS stack per 256-thread workgroup
-    const int shade_grid_max = s->n_cus * 8;
+    const int shade_grid_max = s->n_cus * 2 * RR_SHADE_WAVES;
 
     HIP_TRY(hipEventRecord(s->frame_a, st));
     for (uint64_t first = 0; first < total_primary; first += B) {
@@ -747,7 +751,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         uint32_t* level_count = pool; next_word = R + 4;
         // The batch covers primary indices [first, first + n_batch): index i -> sample i / npix, pixel i % npix.
         hipLaunchKernelGGL(k_raygen, dim3((n_batch + RR_BLOCK - 1) / RR_BLOCK), dim3(RR_BLOCK), 0, st, fr, s->region_xy.as<uint32_t>(),
-                           s->trace_order.as<uint32_t>(), s->sample_xy.as<uint16_t>(), (unsigned long long)first, n_batch, Q[0], &level_count[1], counters);
+                           s->sample_xy.as<uint16_t>(), (unsigned long long)first, n_batch, Q[0], &level_count[1], counters);
         // Depth levels.  The size of the next level is read back once per level (one 4-byte copy + stream
         // sync): launches are then sized by the rays that exist, and empty levels are never launched.
         uint64_t n_level = n_batch;
@@ -762,18 +766,23 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
             for (uint64_t c0 = 0; c0 < n_level; c0 += chunk) {
                 const uint64_t c1 = std::min<uint64_t>(c0 + chunk, n_level);
                 if (next_word + 3 >= POOL_WORDS) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise RR_SHADE_CHUNK");
-                uint32_t* sq_count = word();
                 const int grid = (int)std::min<uint64_t>((c1 - c0 + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)shade_grid_max);
+                const uint32_t L = s->n_enabled_lights;
+                // shadow sub-queues: a shard gets the packets with (packet % RR_SQ_SHARDS == shard), L rays per hit at most
+                const uint64_t groups = (c1 - c0 + RR_BLOCK - 1) / RR_BLOCK; // 256-ray groups, dealt round-robin to the shards
+                const uint32_t segcap = (uint32_t)(((groups + RR_SQ_SHARDS - 1) / RR_SQ_SHARDS) * RR_BLOCK * std::max(L, 1u));
+                if (next_word + RR_SQ_SHARDS + 2 >= POOL_WORDS) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise RR_SHADE_CHUNK");
+                uint32_t* sq_counts = pool + next_word; next_word += RR_SQ_SHARDS;
                 {
                     ScopedTimer t(s, st, 2);
                     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, fr, s->region_xy.as<uint32_t>(), qin, &level_count[d],
-                                       (uint32_t)c0, (uint32_t)c1, qout, &level_count[d + 1], SQ, sq_count, acc, counters);
+                                       (uint32_t)c0, (uint32_t)c1, qout, &level_count[d + 1], SQ, sq_counts, segcap, acc, counters);
                 }
-                if (s->n_enabled_lights) {
+                if (L) {
                     ScopedTimer t(s, st, 1);
-                    const uint64_t sq_ub = (c1 - c0) * s->n_enabled_lights;
+                    const uint64_t sq_ub = (c1 - c0) * L;
                     const int sgrid = (int)std::min<uint64_t>((sq_ub + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)trace_grid);
-                    hipLaunchKernelGGL(k_trace_shadow, dim3(sgrid), dim3(RR_BLOCK), 0, st, s->view, SQ, sq_count, word(), acc);
+                    hipLaunchKernelGGL(k_trace_shadow, dim3(sgrid), dim3(RR_BLOCK), 0, st, s->view, SQ, sq_counts, segcap, word(), acc);
                 }
             }
             if (d == R + 1) break; // the deepest level spawns nothing
@@ -786,7 +795,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         // batches are stream-ordered; only a caller that can cancel needs the host to keep pace with the device
         if (cancel && first + B < total_primary) HIP_TRY(hipStreamSynchronize(st));
     }
-    hipLaunchKernelGGL(k_resolve, dim3((npix + RR_BLOCK - 1) / RR_BLOCK), dim3(RR_BLOCK), 0, st, fr, s->region_xy.as<uint32_t>(), acc,
+    hipLaunchKernelGGL(k_resolve, dim3((npix + RR_BLOCK - 1) / RR_BLOCK), dim3(RR_BLOCK), 0, st, fr, s->region_xy.as<uint32_t>(), s->trace_order.as<uint32_t>(), acc,
                        out->rgba8, out->normal, out->depth, out->object_id, frame_layout ? 1u : 0u);
     HIP_TRY(hipEventRecord(s->frame_b, st));
     HIP_TRY(hipGetLastError());
@@ -913,7 +922,7 @@ extern "C" int rr_pick(rr_scene* s, const rr_camera* cam, int x, int y, rr_pick_
     HIP_TRY(hipMemset(b, 0, 256));
     HIP_TRY(hipMemcpy(b, &h_xy, 4, hipMemcpyHostToDevice));
     DRayQueue q{(float4*)(b + 16), (float4*)(b + 32), (uint2*)(b + 48), (uint4*)(b + 64)};
-    hipLaunchKernelGGL(k_raygen, dim3(1), dim3(RR_BLOCK), 0, nullptr, fr, (const uint32_t*)b, (const uint32_t*)(b + 8), (const uint16_t*)(b + 4), 0ull, 1u, q,
+    hipLaunchKernelGGL(k_raygen, dim3(1), dim3(RR_BLOCK), 0, nullptr, fr, (const uint32_t*)b, (const uint16_t*)(b + 4), 0ull, 1u, q,
                        (uint32_t*)(b + 96), (unsigned long long*)(b + 128));
     hipLaunchKernelGGL(k_trace_closest, dim3(1), dim3(RR_BLOCK), 0, nullptr, s->view, q, (const uint32_t*)(b + 96), (uint32_t*)(b + 100));
     uint32_t hit[4];

@@ -21,7 +21,7 @@ struct DNode { float4 n0, n1, n2, n3; };
 // Depth limits enforced by the host builder, so the fixed LDS stack can never overflow: per level one
 // sentinel entry plus at most one pending sibling per inner node on the path, plus one scratch slot above the
 // top (the node step writes the far child before it knows whether it is needed).
-#define RR_BLAS_MAX_DEPTH 25
+#define RR_BLAS_MAX_DEPTH 24
 #define RR_TLAS_MAX_DEPTH 12
 #ifndef RR_STACK_DEPTH
 #define RR_STACK_DEPTH (RR_BLAS_MAX_DEPTH + RR_TLAS_MAX_DEPTH + 3)
@@ -121,7 +121,7 @@ struct DFrame {
 
 // ---- ray queues (SoA of 16-byte groups, 56 B per ray) -------------------------------------
 //   r0 = (origin.xyz, throughput)
-//   r1 = (dir.xyz (normalised), bits(region pixel index))
+//   r1 = (dir.xyz (normalised), bits(accumulator slot of the pixel))
 //   r2 = (sample | depth << 16 | idcarrier << 24, path node index)
 //   hit = (bits(toi), item index or -1, face id (+ n_tris for back faces), 0)
 struct DRayQueue {
@@ -134,7 +134,7 @@ struct DRayQueue {
 // shadow-ray queue, 64 B per ray
 //   s0 = (origin.xyz, limit)      limit = distance to the light, or +FLT_MAX for directional lights
 //   s1 = (dir.xyz, receiver material alpha)
-//   s2 = (contribution rgb, bits(region pixel index))
+//   s2 = (contribution rgb, bits(accumulator slot))
 //   s3 = (receiver item, depth, 0, 0)
 struct DShadowQueue {
     float4* s0;
@@ -147,11 +147,14 @@ struct DShadowQueue {
 #define RR_FIX_SCALE 16777216.0f
 #define RR_FIX_CLAMP 32768.0f
 #define RR_DEPTH_SCALE 65536.0f
+// Indexed by ACCUMULATOR SLOT: slots enumerate the region's pixels in trace order (8x8 blocks inside the
+// tiles), so a wave of primary rays adds to 64 consecutive words of a plane.
 struct DAccum {
-    long long* rgb;    // n_region_pixels * 3
-    long long* normal; // n_region_pixels * 3
-    long long* depth;  // n_region_pixels
-    uint32_t* object_id; // n_region_pixels
+    long long* rgb;    // 3 planes of n
+    long long* normal; // 3 planes of n
+    long long* depth;  // n
+    uint32_t* object_id; // n
+    unsigned long long n; // slots = pixels of the region
 };
 
 // device-side counters (one block of 64-bit words)

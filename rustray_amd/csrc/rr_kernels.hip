@@ -24,6 +24,7 @@
 #include "rr_math.h"
 
 #define RR_BLOCK 256
+#define RR_SQ_SHARDS 32 // sub-queues of the shadow queue, one append counter each
 #ifndef RR_TRACE_WAVES
 #define RR_TRACE_WAVES 4 // waves per SIMD the trace kernels are built for (bounds VGPRs; LDS stack: RR_STACK_DEPTH KB per workgroup)
 #endif
@@ -550,18 +551,33 @@ RR_DEV long long to_fix(float v, float scale, float clampv) {
     return __float2ll_rn(v * scale);
 }
 RR_DEV void accum_rgb(const DAccum& acc, uint32_t pix, float r, float g, float b) {
+#ifdef RR_EXP_NO_ATOMICS
+    if (r == 123.456f) acc.rgb[pix] = 0; // timing experiment only
+    return;
+#endif
     long long fr = to_fix(r, RR_FIX_SCALE, RR_FIX_CLAMP), fg = to_fix(g, RR_FIX_SCALE, RR_FIX_CLAMP), fb = to_fix(b, RR_FIX_SCALE, RR_FIX_CLAMP);
-    unsigned long long* p = (unsigned long long*)(acc.rgb + 3ull * pix);
-    if (fr) atomicAdd(p + 0, (unsigned long long)fr);
-    if (fg) atomicAdd(p + 1, (unsigned long long)fg);
-    if (fb) atomicAdd(p + 2, (unsigned long long)fb);
+    // one plane per channel: the 64 lanes of a wave of primary rays add to 64 consecutive words (8 x 64-B requests)
+    unsigned long long* p = (unsigned long long*)acc.rgb + pix;
+    if (fr) atomicAdd(p, (unsigned long long)fr);
+    if (fg) atomicAdd(p + acc.n, (unsigned long long)fg);
+    if (fb) atomicAdd(p + 2ull * acc.n, (unsigned long long)fb);
 }
 
-// persistent packet fetch: one atomic per wave hands out 64 consecutive queue slots
-RR_DEV uint32_t wave_fetch(uint32_t* head, uint32_t lane) {
+// Persistent packet fetch: one atomic per wave hands out RR_FETCH packets of 64 consecutive queue slots.
+// (One returning atomic on a single word sustains ~90 per microsecond on MI355X: at one per 64 rays that
+// alone caps a kernel at ~5.6 G rays/s and was the limiter of k_shade's queue appends, see DESIGN.md.)
+#ifndef RR_FETCH
+#define RR_FETCH 2 // measured on sponza_syn: 1 -> 36.2, 2 -> 32.4, 4 -> 42.3 ms in k_trace_closest
+#endif
+RR_DEV uint32_t wave_fetch(uint32_t* head, uint32_t lane, uint32_t packets) {
     uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(head, (uint32_t)RR_WAVE);
+    if (lane == 0) base = atomicAdd(head, (uint32_t)RR_WAVE * packets);
     return __shfl(base, 0) + lane;
+}
+// RR_FETCH packets per fetch once every wave of the grid can get that many, else one (short launches of the
+// deep levels would otherwise leave half of the waves idle while the others walk two packets in a row)
+RR_DEV uint32_t fetch_packets(uint32_t n) {
+    return (n >= gridDim.x * (RR_BLOCK / RR_WAVE) * RR_WAVE * RR_FETCH) ? (uint32_t)RR_FETCH : 1u;
 }
 
 // ---------------------------------------------------------------------------
@@ -574,8 +590,7 @@ RR_DEV float4 mat4_mul(const float* m, float x, float y, float z, float w) {
                        ((m[3] * x + m[7] * y) + m[11] * z) + m[15] * w);
 }
 
-__global__ __launch_bounds__(RR_BLOCK) void k_raygen(DFrame fr, const uint32_t* __restrict__ region_xy,
-                                                     const uint32_t* __restrict__ trace_order,
+__global__ __launch_bounds__(RR_BLOCK) void k_raygen(DFrame fr, const uint32_t* __restrict__ slot_xy,
                                                      const uint16_t* __restrict__ sample_xy,
                                                      unsigned long long first, uint32_t n_rays, DRayQueue q,
                                                      uint32_t* q_count, unsigned long long* counters) {
@@ -583,9 +598,9 @@ __global__ __launch_bounds__(RR_BLOCK) void k_raygen(DFrame fr, const uint32_t* 
     if (i == 0) { *q_count = n_rays; atomicAdd(&counters[RR_CNT_PRIMARY], (unsigned long long)n_rays); }
     if (i >= n_rays) return;
     const unsigned long long gi = first + i; // sample-major index over the region: sample = gi / n_pix
-    uint32_t pix = trace_order[(uint32_t)(gi % fr.n_region_pixels)]; // 8x8 blocks of the region's tiles
+    uint32_t pix = (uint32_t)(gi % fr.n_region_pixels); // accumulator slot: slots enumerate 8x8 blocks of the region's tiles
     uint32_t s = (uint32_t)(gi / fr.n_region_pixels);
-    uint32_t xy = region_xy[pix];
+    uint32_t xy = slot_xy[pix];
     float x_f = (float)(xy & 0xffffu), y_f = (float)(xy >> 16);
     float w = (float)fr.width, h = (float)fr.height;
     float x_step = 2.0f / w, y_step = 2.0f / h;
@@ -639,15 +654,20 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_closest(DSce
     __shared__ int s_stack[RR_STACK_DEPTH * RR_BLOCK];
     const uint32_t n = *q_count;
     const uint32_t lane = threadIdx.x & (RR_WAVE - 1);
+    const uint32_t fetch = fetch_packets(n);
     for (;;) {
-        uint32_t i = wave_fetch(head, lane);
-        if (__builtin_amdgcn_readfirstlane(i) >= n) break; // whole packet beyond the end: wave-uniform exit
-        if (i < n) {
-            float4 r0 = q.r0[i], r1 = q.r1[i];
-            uint32_t depth = (q.r2[i].x >> 16) & 0xffu;
-            Closest best;
-            trace_closest_ray(sc, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), depth, s_stack, &best);
-            q.hit[i] = make_uint4(__float_as_uint(best.t), (uint32_t)(best.found ? best.item : -1), best.face, 0u);
+        const uint32_t i0 = wave_fetch(head, lane, fetch);
+        if (__builtin_amdgcn_readfirstlane(i0) >= n) break; // whole fetch beyond the end: wave-uniform exit
+#pragma unroll 1
+        for (uint32_t p = 0; p < fetch; p++) {
+            const uint32_t i = i0 + p * RR_WAVE;
+            if (i < n) {
+                float4 r0 = q.r0[i], r1 = q.r1[i];
+                uint32_t depth = (q.r2[i].x >> 16) & 0xffu;
+                Closest best;
+                trace_closest_ray(sc, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), depth, s_stack, &best);
+                q.hit[i] = make_uint4(__float_as_uint(best.t), (uint32_t)(best.found ? best.item : -1), best.face, 0u);
+            }
         }
     }
 }
@@ -677,11 +697,14 @@ RR_DEV float4 item_color(const DSceneView& sc, const DMaterial& m, bool has_uv, 
 // ---------------------------------------------------------------------------
 // kernel 3: shade one depth level (reference src/raytracing.rs:734-995)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(RR_BLOCK) void k_shade(DSceneView sc, DFrame fr, const uint32_t* __restrict__ region_xy,
+#ifndef RR_SHADE_WAVES
+#define RR_SHADE_WAVES 4
+#endif
+__global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView sc, DFrame fr, const uint32_t* __restrict__ slot_xy,
                                                     DRayQueue qin, const uint32_t* __restrict__ qin_count,
                                                     uint32_t chunk_begin, uint32_t chunk_end,
                                                     DRayQueue qout, uint32_t* qout_count,
-                                                    DShadowQueue sq, uint32_t* sq_count,
+                                                    DShadowQueue sq, uint32_t* sq_counts, uint32_t sq_segcap,
                                                     DAccum acc, unsigned long long* counters) {
     const uint32_t n = min(*qin_count, chunk_end);
     const uint32_t lane = threadIdx.x & (RR_WAVE - 1);
@@ -691,10 +714,18 @@ __global__ __launch_bounds__(RR_BLOCK) void k_shade(DSceneView sc, DFrame fr, co
     const uint32_t wave_stride = gridDim.x * (RR_BLOCK / RR_WAVE) * RR_WAVE;
     for (uint32_t base = chunk_begin + wave_global * RR_WAVE; base < n; base += wave_stride) {
         const uint32_t i = base + lane;
-        if (i >= n) continue;
-        const uint4 hit = qin.hit[i];
+        uint4 hit = make_uint4(0u, 0xffffffffu, 0u, 0u);
+        if (i < n) hit = qin.hit[i];
         const int item_idx = (int)hit.y;
-        if (item_idx < 0) continue; // miss: colour 0, depth 0, normal 0, id 0 (:728-732); buffers are pre-zeroed
+        const bool active = i < n && item_idx >= 0; // miss: colour 0, depth 0, normal 0, id 0 (:728-732); buffers are pre-zeroed
+        // Shadow rays are appended densely (ballot + prefix, one atomic per wave and light) to one of
+        // RR_SQ_SHARDS sub-queues chosen by the input packet group (256 consecutive rays): a single append counter is a hot word
+        // (~90 returning atomics per microsecond) that capped this kernel at one 64-ray packet per ~11 ns.
+        // Shard capacity is static: a shard receives at most its share of the chunk's packets.
+        const uint32_t shard = ((base - chunk_begin) / RR_BLOCK) % RR_SQ_SHARDS; // the 4 packets of a workgroup iteration stay together
+        uint32_t* const sq_count = sq_counts + shard;
+        const uint32_t sq_base = shard * sq_segcap;
+        if (!active) continue;
         n_shaded++;
         const float4 r0 = qin.r0[i], r1 = qin.r1[i];
         const uint2 r2 = qin.r2[i];
@@ -740,10 +771,10 @@ __global__ __launch_bounds__(RR_BLOCK) void k_shade(DSceneView sc, DFrame fr, co
         if (depth == 1u) {
             if (acc.depth) atomicAdd((unsigned long long*)(acc.depth + pix), (unsigned long long)to_fix(hit_dist, RR_DEPTH_SCALE, 1.0e9f));
             if (acc.normal) {
-                unsigned long long* np = (unsigned long long*)(acc.normal + 3ull * pix);
-                atomicAdd(np + 0, (unsigned long long)to_fix(normal.x, RR_FIX_SCALE, RR_FIX_CLAMP));
-                atomicAdd(np + 1, (unsigned long long)to_fix(normal.y, RR_FIX_SCALE, RR_FIX_CLAMP));
-                atomicAdd(np + 2, (unsigned long long)to_fix(normal.z, RR_FIX_SCALE, RR_FIX_CLAMP));
+                unsigned long long* np = (unsigned long long*)acc.normal + pix;
+                atomicAdd(np, (unsigned long long)to_fix(normal.x, RR_FIX_SCALE, RR_FIX_CLAMP));
+                atomicAdd(np + acc.n, (unsigned long long)to_fix(normal.y, RR_FIX_SCALE, RR_FIX_CLAMP));
+                atomicAdd(np + 2ull * acc.n, (unsigned long long)to_fix(normal.z, RR_FIX_SCALE, RR_FIX_CLAMP));
             }
         }
         // ---- uv (:749-754)
@@ -769,8 +800,8 @@ __global__ __launch_bounds__(RR_BLOCK) void k_shade(DSceneView sc, DFrame fr, co
             t.z = (tangent.z * nm.x + bitangent.z * nm.y) + normal.z * nm.z;
             surface_normal = normalize3(t);
         }
-        // the generator is keyed on the FRAME pixel (y * width + x), never on the region slot
-        const uint32_t xy = region_xy[pix];
+        // the generator is keyed on the FRAME pixel (y * width + x), never on the accumulator slot
+        const uint32_t xy = slot_xy[pix];
         RngKey rk; rk.seed_lo = fr.seed_lo; rk.seed_hi = fr.seed_hi;
         rk.pixel = (xy >> 16) * fr.width + (xy & 0xffffu); rk.sample = sample; rk.node = node;
         const bool mc = fr.monte_carlo != 0u && (m.flags & RR_MF_MONTE_CARLO) != 0u;
@@ -868,7 +899,7 @@ __global__ __launch_bounds__(RR_BLOCK) void k_shade(DSceneView sc, DFrame fr, co
             const bool nonzero = (cr != 0.0f) || (cg != 0.0f) || (cb != 0.0f);
             const bool want_shadow = (m.flags & RR_MF_RECEIVE_SHADOW) != 0u && nonzero;
             if (!(m.flags & RR_MF_RECEIVE_SHADOW) && nonzero) accum_rgb(acc, pix, cr, cg, cb);
-            const uint32_t si = wave_alloc(sq_count, want_shadow, lane);
+            const uint32_t si = sq_base + wave_alloc(sq_count, want_shadow, lane);
             if (want_shadow) {
                 f3 so = hit_point + (surface_normal * 0.001f);
                 f3 sd = to_light;
@@ -922,17 +953,35 @@ __global__ __launch_bounds__(RR_BLOCK) void k_shade(DSceneView sc, DFrame fr, co
 // ---------------------------------------------------------------------------
 // kernel 4: shadow rays of one shade chunk (reference src/raytracing.rs:872-914)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DSceneView sc, DShadowQueue sq, const uint32_t* __restrict__ sq_count,
+__global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DSceneView sc, DShadowQueue sq, const uint32_t* __restrict__ sq_counts, uint32_t sq_segcap,
                                                            uint32_t* head, DAccum acc) {
     __shared__ int s_stack[RR_STACK_DEPTH * RR_BLOCK];
-    const uint32_t n = *sq_count;
+    __shared__ uint32_t s_prefix[RR_SQ_SHARDS + 1];
+    // dense index space over the shards: prefix sums of their counts
+    if (threadIdx.x < RR_WAVE) {
+        uint32_t c = threadIdx.x < RR_SQ_SHARDS ? sq_counts[threadIdx.x] : 0u;
+        uint32_t incl = c;
+        for (int off = 1; off < RR_SQ_SHARDS; off <<= 1) { uint32_t v = __shfl_up(incl, off); if ((int)threadIdx.x >= off) incl += v; }
+        if (threadIdx.x < RR_SQ_SHARDS) s_prefix[threadIdx.x + 1] = incl;
+        if (threadIdx.x == 0) s_prefix[0] = 0u;
+    }
+    __syncthreads();
+    const uint32_t n = s_prefix[RR_SQ_SHARDS];
     const uint32_t lane = threadIdx.x & (RR_WAVE - 1);
     const bool gw = sc.general_w != 0u;
+    const uint32_t fetch = 1u; // shadow rays differ too much in cost (early exit vs full walk): two-packet fetches cost 20 % on helmet_syn
     for (;;) {
-        uint32_t i = wave_fetch(head, lane);
-        if (__builtin_amdgcn_readfirstlane(i) >= n) break;
-        if (i < n) {
-            const float4 s0 = sq.s0[i], s1 = sq.s1[i], s2 = sq.s2[i];
+        const uint32_t i0 = wave_fetch(head, lane, fetch);
+        if (__builtin_amdgcn_readfirstlane(i0) >= n) break;
+#pragma unroll 1
+        for (uint32_t p = 0; p < fetch; p++) {
+        const uint32_t j = i0 + p * RR_WAVE;
+        if (j < n) {
+            uint32_t lo = 0, hi = RR_SQ_SHARDS; // largest shard with prefix <= j
+            while (hi - lo > 1u) { uint32_t mid = (lo + hi) >> 1; if (s_prefix[mid] <= j) lo = mid; else hi = mid; }
+            const uint32_t i = lo * sq_segcap + (j - s_prefix[lo]);
+            const float4 s0 = sq.s0[i];
+            const float4 s1 = sq.s1[i], s2 = sq.s2[i];
             const uint4 s3 = sq.s3[i];
             const f3 o = mk3(s0.x, s0.y, s0.z), d = mk3(s1.x, s1.y, s1.z);
             ShadowSel sel;
@@ -957,25 +1006,28 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DScen
             }
             accum_rgb(acc, __float_as_uint(s2.w), s2.x * factor, s2.y * factor, s2.z * factor);
         }
+        }
     }
 }
 
 // ---------------------------------------------------------------------------
 // kernel 5: resolve accumulators into PixelData (reference src/raytracing.rs:406-426)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(RR_BLOCK) void k_resolve(DFrame fr, const uint32_t* __restrict__ region_xy, DAccum acc,
+__global__ __launch_bounds__(RR_BLOCK) void k_resolve(DFrame fr, const uint32_t* __restrict__ slot_xy,
+                                                      const uint32_t* __restrict__ slot_out, DAccum acc,
                                                       uint8_t* rgba8, float* normal, float* depth, uint32_t* object_id,
                                                       uint32_t frame_layout) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; // accumulator slot
     if (p >= fr.n_region_pixels) return;
-    uint32_t o = p;
-    if (frame_layout) { uint32_t xy = region_xy[p]; o = (xy >> 16) * fr.width + (xy & 0xffffu); }
+    uint32_t o;
+    if (frame_layout) { uint32_t xy = slot_xy[p]; o = (xy >> 16) * fr.width + (xy & 0xffffu); }
+    else o = slot_out[p]; // position in the region's compact output order
     const double inv_fix = 1.0 / 16777216.0;
     const float n = (float)fr.samples;
     float c[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        float sum = (float)((double)acc.rgb[3ull * p + k] * inv_fix);
+        float sum = (float)((double)acc.rgb[(unsigned long long)k * acc.n + p] * inv_fix);
         float v = sum / n;
         c[k] = rs_min(v, 1.0f);
     }
@@ -988,8 +1040,8 @@ __global__ __launch_bounds__(RR_BLOCK) void k_resolve(DFrame fr, const uint32_t*
     }
     ((uint32_t*)rgba8)[o] = r | (g << 8) | (b << 16) | (255u << 24);
     if (normal && acc.normal) {
-        f3 nn = mk3((float)((double)acc.normal[3ull * p] * inv_fix) / n, (float)((double)acc.normal[3ull * p + 1] * inv_fix) / n,
-                    (float)((double)acc.normal[3ull * p + 2] * inv_fix) / n);
+        f3 nn = mk3((float)((double)acc.normal[p] * inv_fix) / n, (float)((double)acc.normal[acc.n + p] * inv_fix) / n,
+                    (float)((double)acc.normal[2ull * acc.n + p] * inv_fix) / n);
         nn = normalize3(nn); // 0/0 = NaN on all-miss pixels, as in the reference (:426)
         normal[3ull * o] = nn.x; normal[3ull * o + 1] = nn.y; normal[3ull * o + 2] = nn.z;
     }
