@@ -93,6 +93,9 @@ RR_DEV bool aabb_cast(const float* mins, const float* maxs, const LRay& ray, boo
 // (v = -ac.e | ac.e, w = ab.e | -ab.e, toi = -t/d | t/d; negation is exact), rejections keep parry's
 // comparison forms so NaNs fall through exactly as they do there; the division runs for accepted hits only.
 RR_DEV bool ray_triangle(f3 a, f3 b, f3 c, const LRay& ray, float* toi_out, uint32_t* side_out) {
+#ifdef RR_ABLATE_TRI
+    if (a.x != 123.456f) return false; // timing experiment: triangles are fetched but never tested
+#endif
     const f3 ab = b - a, ac = c - a;
     const f3 n = cross3(ab, ac);
     const float d = dot3(n, ray.d);
@@ -319,6 +322,9 @@ RR_DEV void closest_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t dep
         if (!ray_ball(it.radius, lr, solid, &t, &inside)) return;
         face = 0u;
     } else {
+#ifdef RR_ABLATE_BLAS
+        if (it.radius != 123.456f) return; // timing experiment: per-mesh trees are never entered
+#endif
         if (it.n_tris == 0u) return;
         TriBest tb;
         blas_closest(sc, it, lr, best->found ? best->t : RR_FLT_MAX, s_stack, sp_base, &tb);
@@ -566,6 +572,10 @@ RR_DEV void accum_rgb(const DAccum& acc, uint32_t pix, float r, float g, float b
 // Persistent packet fetch: one atomic per wave hands out RR_FETCH packets of 64 consecutive queue slots.
 // (One returning atomic on a single word sustains ~90 per microsecond on MI355X: at one per 64 rays that
 // alone caps a kernel at ~5.6 G rays/s and was the limiter of k_shade's queue appends, see DESIGN.md.)
+#ifndef RR_STATIC_NUM
+#define RR_STATIC_NUM 3
+#define RR_STATIC_DEN 4
+#endif
 #ifndef RR_FETCH
 #define RR_FETCH 2 // measured on sponza_syn: 1 -> 36.2, 2 -> 32.4, 4 -> 42.3 ms in k_trace_closest
 #endif
@@ -654,20 +664,38 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_closest(DSce
     __shared__ int s_stack[RR_STACK_DEPTH * RR_BLOCK];
     const uint32_t n = *q_count;
     const uint32_t lane = threadIdx.x & (RR_WAVE - 1);
-    const uint32_t fetch = fetch_packets(n);
+    // Work distribution.  Locality decides here: the waves that run side by side must walk neighbouring
+    // packets (runs of consecutive packets per wave cost 1.8x, measured), and one head word sustains only ~90
+    // fetches per microsecond.  So RR_STATIC_NUM/RR_STATIC_DEN of the packets are dealt round-robin with no atomic
+    // at all, and only the tail is pulled one packet at a time from the shared head to absorb expensive packets.
+    // Blocks b and b + 8 share an XCD (and its L2): with RR_XCD_SWIZZLE the blocks of one XCD take one
+    // contiguous run of packets per round instead of every eighth group.
+    const uint32_t n_waves = gridDim.x * (RR_BLOCK / RR_WAVE);
+    uint32_t blk = blockIdx.x;
+#ifndef RR_NO_XCD_SWIZZLE
+    if ((gridDim.x & 7u) == 0u) blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#endif
+    const uint32_t wave_id = blk * (RR_BLOCK / RR_WAVE) + threadIdx.x / RR_WAVE;
+    const uint32_t n_packets = (n + RR_WAVE - 1) / RR_WAVE;
+    const uint32_t rounds = (uint32_t)(((unsigned long long)n_packets * RR_STATIC_NUM / RR_STATIC_DEN) / n_waves);
+    const uint32_t n_static = rounds * n_waves;
+    uint32_t round = 0;
     for (;;) {
-        const uint32_t i0 = wave_fetch(head, lane, fetch);
-        if (__builtin_amdgcn_readfirstlane(i0) >= n) break; // whole fetch beyond the end: wave-uniform exit
-#pragma unroll 1
-        for (uint32_t p = 0; p < fetch; p++) {
-            const uint32_t i = i0 + p * RR_WAVE;
-            if (i < n) {
-                float4 r0 = q.r0[i], r1 = q.r1[i];
-                uint32_t depth = (q.r2[i].x >> 16) & 0xffu;
-                Closest best;
-                trace_closest_ray(sc, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), depth, s_stack, &best);
-                q.hit[i] = make_uint4(__float_as_uint(best.t), (uint32_t)(best.found ? best.item : -1), best.face, 0u);
-            }
+        uint32_t pkt;
+        if (round < rounds) { pkt = round * n_waves + wave_id; round++; }
+        else {
+            uint32_t f = 0;
+            if (lane == 0) f = atomicAdd(head, 1u);
+            pkt = n_static + __shfl(f, 0);
+        }
+        if (pkt >= n_packets) break; // wave-uniform
+        const uint32_t i = pkt * RR_WAVE + lane;
+        if (i < n) {
+            float4 r0 = q.r0[i], r1 = q.r1[i];
+            uint32_t depth = (q.r2[i].x >> 16) & 0xffu;
+            Closest best;
+            trace_closest_ray(sc, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), depth, s_stack, &best);
+            q.hit[i] = make_uint4(__float_as_uint(best.t), (uint32_t)(best.found ? best.item : -1), best.face, 0u);
         }
     }
 }
@@ -969,13 +997,15 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DScen
     const uint32_t n = s_prefix[RR_SQ_SHARDS];
     const uint32_t lane = threadIdx.x & (RR_WAVE - 1);
     const bool gw = sc.general_w != 0u;
-    const uint32_t fetch = 1u; // shadow rays differ too much in cost (early exit vs full walk): two-packet fetches cost 20 % on helmet_syn
+    const uint32_t n_packets = (n + RR_WAVE - 1) / RR_WAVE;
     for (;;) {
-        const uint32_t i0 = wave_fetch(head, lane, fetch);
-        if (__builtin_amdgcn_readfirstlane(i0) >= n) break;
-#pragma unroll 1
-        for (uint32_t p = 0; p < fetch; p++) {
-        const uint32_t j = i0 + p * RR_WAVE;
+        // shadow rays differ a lot in cost (early exit vs full walk): one packet per fetch balances best
+        uint32_t p = 0;
+        if (lane == 0) p = atomicAdd(head, 1u);
+        p = __shfl(p, 0);
+        if (p >= n_packets) break;
+        {
+        const uint32_t j = p * RR_WAVE + lane;
         if (j < n) {
             uint32_t lo = 0, hi = RR_SQ_SHARDS; // largest shard with prefix <= j
             while (hi - lo > 1u) { uint32_t mid = (lo + hi) >> 1; if (s_prefix[mid] <= j) lo = mid; else hi = mid; }
