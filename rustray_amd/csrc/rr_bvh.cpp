@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace rr {
@@ -99,8 +100,9 @@ struct Builder {
                 if (n <= max_leaf) {
                     float plo[3], phi[3];
                     bounds(a, b, plo, phi);
-                    // traversal step ~ 1.5 primitive tests
-                    if (best_cost + 1.5f * half_area(plo, phi) >= half_area(plo, phi) * (float)n) return leaf_code(a, n);
+                    // cost of one more traversal step, in primitive tests (RR_SAH_CT overrides, for experiments)
+                    static const float ct = getenv("RR_SAH_CT") ? (float)atof(getenv("RR_SAH_CT")) : 1.5f;
+                    if (best_cost + ct * half_area(plo, phi) >= half_area(plo, phi) * (float)n) return leaf_code(a, n);
                 }
                 float ext = chi[best_axis] - clo[best_axis];
                 float scale = 16.0f / ext;

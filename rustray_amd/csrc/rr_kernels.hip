@@ -943,9 +943,19 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         // ---- children (:938-971), compacted into the next level's queue
         const uint32_t child_meta = sample | ((depth + 1u) << 16);
         {
-            const uint32_t oi = wave_alloc(qout_count, spawn_refl, lane);
+            // one allocation for both kinds of children: reflection rays of the wave first, then refraction rays
+            const unsigned long long m_refl = __ballot(spawn_refl), m_refr = __ballot(spawn_refr);
+            const uint32_t n_refl = (uint32_t)__popcll(m_refl), n_both = n_refl + (uint32_t)__popcll(m_refr);
+            uint32_t obase = 0u;
+            if (n_both) {
+                const int leader = __ffsll((long long)(m_refl | m_refr)) - 1;
+                if ((int)lane == leader) obase = atomicAdd(qout_count, n_both);
+                obase = __shfl(obase, leader);
+            }
+            const unsigned long long below = (1ull << lane) - 1ull;
             if (spawn_refl) {
                 // create_reflection (:492-498)
+                const uint32_t oi = obase + (uint32_t)__popcll(m_refl & below);
                 f3 o2 = hit_point + (surface_normal * 0.001f);
                 f3 d2 = normalize3(rd - ((2.0f * dot3(rd, surface_normal)) * surface_normal));
                 qout.r0[oi] = make_float4(o2.x, o2.y, o2.z, w_refl);
@@ -953,10 +963,8 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
                 qout.r2[oi] = make_uint2(child_meta, node * 2u);
                 n_secondary++;
             }
-        }
-        {
-            const uint32_t oi = wave_alloc(qout_count, spawn_refr, lane);
             if (spawn_refr) {
+                const uint32_t oi = obase + n_refl + (uint32_t)__popcll(m_refr & below);
                 f3 d2 = normalize3(refr_d);
                 qout.r0[oi] = make_float4(refr_o.x, refr_o.y, refr_o.z, w_refr);
                 qout.r1[oi] = make_float4(d2.x, d2.y, d2.z, __uint_as_float(pix));
