@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--spp", type=int, default=128)
     ap.add_argument("--monte-carlo", type=int, default=1)
-    ap.add_argument("--cpu-spp", type=int, default=8)
+    ap.add_argument("--cpu-spp", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile", default="32x8")
     args = ap.parse_args()

@@ -620,10 +620,13 @@ static bool trace(const OScene& sc, const Ray& ray, bool stop_on_first_hit, bool
     tl_kind = for_shadow ? 1 : 0;
     const rr_flat_scene* fs = sc.fs;
     struct Cand { int item; float dist; };
-    std::vector<Cand> hits;
-    hits.reserve(fs->n_items);
+    // the reference allocates two Vecs per call (src/raytracing.rs:431,447); the restatement reuses per-thread
+    // buffers so that the CPU baseline is not a malloc benchmark on many-core hosts
+    static thread_local std::vector<Cand> hits;
+    static thread_local std::vector<uint32_t> cand;
+    hits.clear();
+    cand.clear();
     // candidates: all items, or (more than BVH_MIN_ITEMS items) Scene::get_possible_hits_by_ray
-    std::vector<uint32_t> cand;
     if (sc.use_scene_accel) {
         const MeshAccel& acc = sc.scene_accel;
         const float o[3] = {ray.origin.x, ray.origin.y, ray.origin.z};
