@@ -290,6 +290,17 @@ int rr_deinterleave_device(uint32_t width, uint32_t height, uint32_t tile_w, uin
 /* Single-ray query at the pixel centre (reference src/raytracing.rs:237-273). */
 int rr_pick(rr_scene* scene, const rr_camera* camera, int x, int y, rr_pick_result* out);
 
+/* Post-processing of a finished frame (reference run_post_processing, src/post_processing.rs:123-181, called from
+ * Run::post_processing, src/run.rs:588-600): outline on object-id edges (:98-121), then cavity = curvature of the
+ * normal buffer (:77-96), clamp, truncate to u8.  Consumes exactly the buffers rr_render produces.
+ * rr_post_process: host buffers; rr_post_process_device: device buffers on `device`, enqueued on `hip_stream`.
+ * rgba_in and rgba_out may not alias (the reference writes a new image). */
+int rr_post_process(uint32_t width, uint32_t height, int cavity, int outline, const uint8_t* rgba_in,
+                    const float* normal, const uint32_t* object_id, uint8_t* rgba_out, int device);
+int rr_post_process_device(uint32_t width, uint32_t height, int cavity, int outline, const uint8_t* rgba_in,
+                           const float* normal, const uint32_t* object_id, uint8_t* rgba_out, int device,
+                           void* hip_stream);
+
 /* Counters and device timings of the most recent frame on this scene. */
 int rr_scene_last_stats(const rr_scene* scene, rr_frame_stats* out);
 

@@ -121,6 +121,16 @@ def render(fs_struct, cam: rr_camera, cfg: rr_config, sample_xy=None, window=Non
     return out
 
 
+def post_process(rgba, normal, object_id, cavity: bool, outline: bool):
+    h, w = rgba.shape[:2]
+    src = np.ascontiguousarray(rgba, np.uint8)
+    out = np.zeros_like(src)
+    nrm = np.ascontiguousarray(normal, np.float32)
+    ids = np.ascontiguousarray(object_id, np.uint32)
+    lib().rro_post_process(C.c_uint32(w), C.c_uint32(h), C.c_int(int(cavity)), C.c_int(int(outline)), _p(src), _p(nrm), _p(ids), _p(out))
+    return out
+
+
 def pick(fs_struct, cam, x, y):
     r = rr_pick_result()
     lib().rro_pick(C.byref(fs_struct), C.byref(cam), C.c_int(x), C.c_int(y), C.byref(r))

@@ -1328,6 +1328,53 @@ int rro_pick(const rr_flat_scene* fs, const rr_camera* cam, int x, int y, rr_pic
     return 0;
 }
 
+// run_post_processing (reference src/post_processing.rs:24-181), restated line by line
+static float curvature_soft_clamp(float curvature, float control) {
+    if (curvature < 0.5f / control) return curvature * (1.0f - curvature * control);
+    return 0.25f / control;
+}
+int rro_post_process(uint32_t width, uint32_t height, int cavity, int outline, const uint8_t* rgba_in, const float* normals,
+                     const uint32_t* object_ids, uint8_t* rgba_out) {
+    const long long n = (long long)width * height;
+    auto fetch3 = [&](int x, int y, int ox, int oy) -> V3 { // texel_fetch_offset_vec3 (:34-48)
+        long long index = (long long)(y + oy) * (long long)width + (x + ox);
+        if (index < 0 || index >= n) return v3(0, 0, 0);
+        return load3(normals + 3 * index);
+    };
+    auto fetchu = [&](int x, int y, int ox, int oy) -> uint32_t { // texel_fetch_offset_u32 (:50-63)
+        long long index = (long long)(y + oy) * (long long)width + (x + ox);
+        if (index < 0 || index >= n) return 0u;
+        return object_ids[index];
+    };
+    const float ridge = 1.15f, valley = 1.0f;
+    for (uint32_t x = 0; x < width; x++)
+        for (uint32_t y = 0; y < height; y++) {
+            const uint8_t* p = rgba_in + 4 * ((size_t)y * width + x);
+            float r = (float)p[0], g = (float)p[1], b = (float)p[2];
+            if (outline) { // calculate_outline (:98-121)
+                uint32_t center = fetchu((int)x, (int)y, 0, 0);
+                uint32_t up = fetchu((int)x, (int)y, 0, 1), down = fetchu((int)x, (int)y, 0, -1);
+                uint32_t rgt = fetchu((int)x, (int)y, -1, 0), lft = fetchu((int)x, (int)y, 1, 0); // names as in the reference
+                float e0 = up == center ? 1.0f : 0.0f, e1 = down == center ? 1.0f : 0.0f, e2 = rgt == center ? 1.0f : 0.0f, e3 = lft == center ? 1.0f : 0.0f;
+                float dot4 = (e0 * 0.25f + e2 * 0.25f) + (e1 * 0.25f + e3 * 0.25f); // nalgebra 4-lane dot order [recalled]
+                float opacity = 1.0f - dot4;
+                if (opacity > 0.0f) { r = opacity * 255.0f; g = opacity * 255.0f; b = opacity * 255.0f; }
+            }
+            if (cavity) { // calculate_curvature (:77-96): .xz() of the four neighbours
+                V3 nu = fetch3((int)x, (int)y, 0, 1), nd = fetch3((int)x, (int)y, 0, -1), nl = fetch3((int)x, (int)y, -1, 0), nr = fetch3((int)x, (int)y, 1, 0);
+                float diff = (nu.z - nd.z) + (nr.x - nl.x);
+                float curvature = diff < 0.0f ? -2.0f * curvature_soft_clamp(-diff, valley) : 2.0f * curvature_soft_clamp(diff, ridge);
+                r *= curvature + 1.0f; g *= curvature + 1.0f; b *= curvature + 1.0f;
+            }
+            r = (r < 0.0f) ? 0.0f : ((r > 255.0f) ? 255.0f : r); // f32::clamp keeps NaN
+            g = (g < 0.0f) ? 0.0f : ((g > 255.0f) ? 255.0f : g);
+            b = (b < 0.0f) ? 0.0f : ((b > 255.0f) ? 255.0f : b);
+            uint8_t* q = rgba_out + 4 * ((size_t)y * width + x);
+            q[0] = as_u8(r); q[1] = as_u8(g); q[2] = as_u8(b); q[3] = 255;
+        }
+    return 0;
+}
+
 // ---- unit-level entry points for known-answer tests -------------------------
 int rro_ray_aabb(const float* mins, const float* maxs, const float* origin, const float* dir, int solid, float* toi) {
     Ray r{load3(origin), load3(dir)};

@@ -20,7 +20,7 @@ _LIB = None
 
 EXPORTS = ["rr_device_count", "rr_last_error", "rr_scene_create", "rr_scene_destroy", "rr_scene_update_transforms",
            "rr_sample_table", "rr_render", "rr_region_pixel_count", "rr_render_region_device",
-           "rr_deinterleave_device", "rr_pick", "rr_scene_last_stats"]
+           "rr_deinterleave_device", "rr_pick", "rr_scene_last_stats", "rr_post_process", "rr_post_process_device"]
 
 
 class RustrayHipError(RuntimeError):
@@ -61,6 +61,8 @@ def lib():
         L.rr_pick.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.c_int, C.c_int, C.POINTER(rr_pick_result)]
         L.rr_scene_last_stats.argtypes = [C.c_void_p, C.POINTER(rr_frame_stats)]
         L.rr_scene_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.rr_post_process.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.rr_post_process_device.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.rr_math_probe.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_uint64, C.c_int]
         _LIB = L
@@ -169,6 +171,26 @@ class DeviceScene:
 def deinterleave_device(width, height, tile_w, tile_h, n_ranks, elem_bytes, src_ptr, dst_ptr, device, stream_ptr=None):
     _check(lib().rr_deinterleave_device(width, height, tile_w, tile_h, n_ranks, elem_bytes, C.c_void_p(src_ptr),
                                         C.c_void_p(dst_ptr), device, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+
+def post_process(rgba: np.ndarray, normal, object_id, cavity: bool, outline: bool, device: int = 0) -> np.ndarray:
+    """run_post_processing (reference src/post_processing.rs:123-181) on the GPU, host arrays in and out."""
+    h, w = rgba.shape[:2]
+    src = np.ascontiguousarray(rgba, np.uint8)
+    out = np.zeros_like(src)
+    nrm = np.ascontiguousarray(normal, np.float32) if normal is not None else None
+    ids = np.ascontiguousarray(object_id, np.uint32) if object_id is not None else None
+    _check(lib().rr_post_process(w, h, int(cavity), int(outline), src.ctypes.data_as(C.c_void_p),
+                                 nrm.ctypes.data_as(C.c_void_p) if nrm is not None else None,
+                                 ids.ctypes.data_as(C.c_void_p) if ids is not None else None,
+                                 out.ctypes.data_as(C.c_void_p), device))
+    return out
+
+
+def post_process_device(w, h, cavity, outline, rgba_ptr, normal_ptr, id_ptr, out_ptr, device=0, stream_ptr=None):
+    _check(lib().rr_post_process_device(w, h, int(cavity), int(outline), C.c_void_p(rgba_ptr), C.c_void_p(normal_ptr) if normal_ptr else None,
+                                        C.c_void_p(id_ptr) if id_ptr else None, C.c_void_p(out_ptr), device,
+                                        C.c_void_p(stream_ptr) if stream_ptr else None))
 
 
 def math_probe(op: int, a, b=None, c=None, seed: int = 0, device: int = 0):

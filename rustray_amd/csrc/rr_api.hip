@@ -903,6 +903,45 @@ extern "C" int rr_deinterleave_device(uint32_t width, uint32_t height, uint32_t 
 }
 
 // ---------------------------------------------------------------------------
+// post-processing (reference src/post_processing.rs:123-181)
+// ---------------------------------------------------------------------------
+extern "C" int rr_post_process_device(uint32_t width, uint32_t height, int cavity, int outline, const uint8_t* rgba_in,
+                                      const float* normal, const uint32_t* object_id, uint8_t* rgba_out, int device, void* hip_stream) {
+    if (width == 0 || height == 0) return fail(RR_ERR_INVALID_ARGUMENT, "bad frame size %ux%u", width, height);
+    if (!rgba_in || !rgba_out || rgba_in == rgba_out) return fail(RR_ERR_INVALID_ARGUMENT, "rgba_in / rgba_out must be distinct non-NULL buffers");
+    if ((cavity && !normal) || (outline && !object_id)) return fail(RR_ERR_INVALID_ARGUMENT, "cavity needs the normal buffer, outline the object-id buffer");
+    HIP_TRY(hipSetDevice(device));
+    const uint64_t n = (uint64_t)width * height;
+    hipLaunchKernelGGL(k_post_process, dim3((uint32_t)((n + RR_BLOCK - 1) / RR_BLOCK)), dim3(RR_BLOCK), 0, (hipStream_t)hip_stream, width, height,
+                       cavity ? 1u : 0u, outline ? 1u : 0u, (const uint32_t*)rgba_in, normal, object_id, (uint32_t*)rgba_out);
+    HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
+extern "C" int rr_post_process(uint32_t width, uint32_t height, int cavity, int outline, const uint8_t* rgba_in, const float* normal,
+                               const uint32_t* object_id, uint8_t* rgba_out, int device) {
+    if (width == 0 || height == 0) return fail(RR_ERR_INVALID_ARGUMENT, "bad frame size %ux%u", width, height);
+    if (!rgba_in || !rgba_out) return fail(RR_ERR_INVALID_ARGUMENT, "NULL image");
+    if ((cavity && !normal) || (outline && !object_id)) return fail(RR_ERR_INVALID_ARGUMENT, "cavity needs the normal buffer, outline the object-id buffer");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(RR_ERR_NO_DEVICE, "no HIP device available");
+    HIP_TRY(hipSetDevice(device));
+    const size_t n = (size_t)width * height;
+    DevBuf in, out, nrm, ids;
+    HIP_TRY(in.reserve(n * 4)); HIP_TRY(out.reserve(n * 4));
+    HIP_TRY(hipMemcpy(in.p, rgba_in, n * 4, hipMemcpyHostToDevice));
+    if (normal) { HIP_TRY(nrm.reserve(n * 12)); HIP_TRY(hipMemcpy(nrm.p, normal, n * 12, hipMemcpyHostToDevice)); }
+    if (object_id) { HIP_TRY(ids.reserve(n * 4)); HIP_TRY(hipMemcpy(ids.p, object_id, n * 4, hipMemcpyHostToDevice)); }
+    int rc = rr_post_process_device(width, height, cavity, outline, in.as<uint8_t>(), nrm.as<float>(), ids.as<uint32_t>(), out.as<uint8_t>(), device, nullptr);
+    if (rc == RR_OK) {
+        hipError_t e = hipMemcpy(rgba_out, out.p, n * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RR_ERR_DEVICE, "copy back: %s", hipGetErrorString(e));
+    }
+    in.release(); out.release(); nrm.release(); ids.release();
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
 // pick (reference src/raytracing.rs:237-273): pixel-centre ray, one closest-hit query
 // ---------------------------------------------------------------------------
 extern "C" int rr_pick(rr_scene* s, const rr_camera* cam, int x, int y, rr_pick_result* out) {

@@ -1099,7 +1099,53 @@ __global__ __launch_bounds__(RR_BLOCK) void k_gather_frame(const uint32_t* __res
 }
 
 // ---------------------------------------------------------------------------
-// kernel 7: device self-test of the arithmetic contract (tests/test_device_math.py)
+// kernel 7: post-processing (reference src/post_processing.rs:24-181), one thread per pixel.
+// HBM-bound: 24 algorithmic bytes per pixel (RGBA in + normal + object id + RGBA out; the 4-neighbour
+// re-reads come from L1/L2).  Neighbours are addressed by LINEAR index y * width + x and only the linear index is
+// range-checked (:40-45), so x + 1 at the right border reads the first pixel of the next row, as in the reference.
+// ---------------------------------------------------------------------------
+RR_DEV float curvature_soft_clamp(float curvature, float control) {
+    if (curvature < 0.5f / control) return curvature * (1.0f - curvature * control);
+    return 0.25f / control;
+}
+__global__ __launch_bounds__(RR_BLOCK) void k_post_process(uint32_t width, uint32_t height, uint32_t cavity, uint32_t outline,
+                                                           const uint32_t* __restrict__ rgba_in, const float* __restrict__ normal,
+                                                           const uint32_t* __restrict__ object_id, uint32_t* __restrict__ rgba_out) {
+    const long long n = (long long)width * height;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t px = rgba_in[i];
+    float r = (float)(px & 255u), g = (float)((px >> 8) & 255u), b = (float)((px >> 16) & 255u);
+    const long long w = (long long)width;
+    const long long up = i + w, down = i - w, left = i - 1, right = i + 1; // (0,1) (0,-1) (-1,0) (1,0)
+    if (outline) {
+        const uint32_t c = object_id[i];
+        const uint32_t o_up = (up >= 0 && up < n) ? object_id[up] : 0u, o_down = (down >= 0 && down < n) ? object_id[down] : 0u;
+        const uint32_t o_l = (left >= 0 && left < n) ? object_id[left] : 0u, o_r = (right >= 0 && right < n) ? object_id[right] : 0u;
+        // equal_vec . (0.25, 0.25, 0.25, 0.25) in nalgebra's 4-lane order (x*x' + z*z') + (y*y' + w*w'); lanes = (up, down, -1, +1)
+        const float e0 = (o_up == c) ? 1.0f : 0.0f, e1 = (o_down == c) ? 1.0f : 0.0f, e2 = (o_l == c) ? 1.0f : 0.0f, e3 = (o_r == c) ? 1.0f : 0.0f;
+        const float opacity = 1.0f - ((e0 * 0.25f + e2 * 0.25f) + (e1 * 0.25f + e3 * 0.25f));
+        if (opacity > 0.0f) { r = opacity * 255.0f; g = opacity * 255.0f; b = opacity * 255.0f; }
+    }
+    if (cavity) {
+        // .xz() of the neighbour normals: x -> .x, z -> .y
+        const float up_z = (up >= 0 && up < n) ? normal[3 * up + 2] : 0.0f, down_z = (down >= 0 && down < n) ? normal[3 * down + 2] : 0.0f;
+        const float left_x = (left >= 0 && left < n) ? normal[3 * left] : 0.0f, right_x = (right >= 0 && right < n) ? normal[3 * right] : 0.0f;
+        const float diff = (up_z - down_z) + (right_x - left_x);
+        float curvature;
+        if (diff < 0.0f) curvature = -2.0f * curvature_soft_clamp(-diff, 1.0f);
+        else curvature = 2.0f * curvature_soft_clamp(diff, 1.15f);
+        r *= curvature + 1.0f; g *= curvature + 1.0f; b *= curvature + 1.0f;
+    }
+    // f32::clamp(0, 255) keeps NaN, `as u8` maps NaN to 0
+    r = (r < 0.0f) ? 0.0f : ((r > 255.0f) ? 255.0f : r);
+    g = (g < 0.0f) ? 0.0f : ((g > 255.0f) ? 255.0f : g);
+    b = (b < 0.0f) ? 0.0f : ((b > 255.0f) ? 255.0f : b);
+    rgba_out[i] = as_u8(r) | (as_u8(g) << 8) | (as_u8(b) << 16) | (255u << 24);
+}
+
+// ---------------------------------------------------------------------------
+// kernel 8: device self-test of the arithmetic contract (tests/test_device_math.py)
 // op: 0 sincos -> (sin, cos); 1 acos; 2 atan2(a, b); 3 a / b; 4 sqrt(a); 5 jitter(dir = (a, b, c))
 // ---------------------------------------------------------------------------
 __global__ void k_math_probe(int op, const float* a, const float* b, const float* c, int n, float* out0, float* out1, float* out2,

@@ -12,7 +12,8 @@ Reference: src/scene.rs:121-157 (load), :159-641 (load_json), :1126-1367
 apply_diff), :708-729 (transform order), :769-772 (material cache);
 src/shape/mesh.rs:166-202, src/shape/sphere.rs:104-118.
 
-glTF loading (src/scene.rs:722-978) is not implemented in this round.
+glTF / GLB scenes (src/scene.rs:722-1124) go through rustray_amd/gltf.py, which restates what the
+`easy-gltf` crate hands to `load_gltf` (world-space de-indexed triangles, split material maps).
 """
 from __future__ import annotations
 
@@ -133,8 +134,10 @@ class Scene:
             ids = self.load_json(path)
         elif ext == ".obj":
             ids = self.load_wavefront(path)
+        elif ext in (".gltf", ".glb"):
+            ids = self.load_gltf(path)
         else:
-            raise NotImplementedError(f"cannot load {path} (glTF loading is not implemented)")
+            raise ValueError(f"can not load {path}")
         return ids
 
     # ---- JSON (src/scene.rs:159-641) -------------------------------------------------
@@ -262,7 +265,10 @@ class Scene:
                 elif item_type == "json":
                     ids = self.load_json(path)
                 else:
-                    raise NotImplementedError("glTF loading is not implemented (asset: %s)" % path)
+                    if not os.path.exists(self._path(path)):
+                        raise FileNotFoundError(f"{path}: the reference downloads this asset at load time (src/scene.rs:470-493); "
+                                                "it is not available offline")
+                    ids = self.load_gltf(path)
                 for item in self.items:
                     if item.id in ids:
                         if obj.get("name") is not None:
@@ -362,6 +368,91 @@ class Scene:
             item.id = self.get_next_id()
             loaded.append(item.id)
             self.items.append(item)
+        return loaded
+
+    # ---- glTF (src/scene.rs:722-1124) ------------------------------------------------------
+    def _add_texture_array(self, rgba: np.ndarray) -> int:
+        self.textures.append(np.ascontiguousarray(rgba, dtype=np.uint8))
+        return len(self.textures) - 1
+
+    def load_gltf(self, path: str) -> List[int]:
+        from . import gltf
+        loaded: List[int] = []
+        double_check: Dict[int, int] = {}   # glTF material identity -> Material id
+        for gscene in gltf.load(self._path(path)):
+            for l in gscene.lights:
+                self.get_next_id()
+                half_pi = _f32(F32(math.pi) / F32(2.0))
+                if l.kind == "point":       # intensity / 10 (src/scene.rs:747)
+                    self.lights.append(Light(pos=l.position, dir=(0.0, -1.0, 0.0), color=l.color, intensity=_f32(F32(l.intensity) / F32(10.0)),
+                                             max_angle=half_pi, light_type=RR_LIGHT_POINT))
+                elif l.kind == "directional":
+                    self.lights.append(Light(pos=(0.0, 0.0, 0.0), dir=l.direction, color=l.color, intensity=l.intensity,
+                                             max_angle=half_pi, light_type=RR_LIGHT_DIRECTIONAL))
+                else:
+                    self.lights.append(Light(pos=l.position, dir=l.direction, color=l.color, intensity=l.intensity,
+                                             max_angle=l.outer_cone_angle, light_type=RR_LIGHT_SPOT))
+            if gscene.cameras:
+                cam = gscene.cameras[0]
+                t = cam.transform
+                fwd, up = t[:3, 2] / np.linalg.norm(t[:3, 2]), t[:3, 1] / np.linalg.norm(t[:3, 1])
+                self.cam.eye_pos = np.asarray(t[:3, 3], dtype=np.float64)
+                d = -fwd
+                self.cam.dir = d / np.linalg.norm(d)
+                self.cam.up = up / np.linalg.norm(up)
+                self.cam.fov = cam.yfov
+                self.cam.clipping_near, self.cam.clipping_far = cam.znear, cam.zfar
+            for model in gscene.models:
+                object_id = self.get_next_id()
+                gm = model.material
+                key = id(gm)
+                if key in double_check:
+                    material_id = double_check[key]
+                else:
+                    material_id = self.get_next_id()
+                    m = Material()
+                    bc = gm.base_color_factor
+                    m.base_color = (bc[0], bc[1], bc[2])
+                    m.specular_color = tuple(_f32(F32(c) * F32(0.8)) for c in m.base_color)
+                    m.alpha = bc[3]
+                    m.reflectivity = _f32(F32(gm.metallic_factor) * F32(0.5))
+                    m.roughness = _f32((F32(1.0) / F32(math.pi) / F32(2.0)) * F32(gm.roughness_factor))
+                    # texture re-packing of get_dyn_image_from_gltf_material (src/scene.rs:980-1124)
+                    if gm.base_color_texture is not None:
+                        m.texture[0] = self._add_texture_array(gm.base_color_texture)
+                    if gm.normal_texture is not None:
+                        n = gm.normal_texture
+                        m.texture[3] = self._add_texture_array(np.concatenate([n, np.full(n.shape[:2] + (1,), 255, np.uint8)], axis=2))
+                    if gm.metallic_texture is not None:
+                        m.texture[7] = self._add_texture_array(np.repeat(gm.metallic_texture[:, :, None], 4, axis=2))
+                    if gm.emissive_texture is not None:
+                        e = gm.emissive_texture
+                        m.texture[1] = self._add_texture_array(np.concatenate([e, np.full(e.shape[:2] + (1,), 255, np.uint8)], axis=2))
+                        m.ambient_color = tuple(gm.emissive_factor)
+                    if gm.roughness_texture is not None:
+                        m.texture[5] = self._add_texture_array(np.repeat(gm.roughness_texture[:, :, None], 4, axis=2))
+                    if gm.occlusion_texture is not None:
+                        # (pixel as f32 * factor) as u8: truncating, saturating
+                        occ = np.clip(np.trunc(gm.occlusion_texture.astype(np.float32) * F32(gm.occlusion_factor)), 0, 255).astype(np.uint8)
+                        m.texture[6] = self._add_texture_array(np.repeat(occ[:, :, None], 4, axis=2))
+                    self.materials[material_id] = m
+                    self.material_tex_paths[material_id] = {}
+                    double_check[key] = material_id
+                nv = len(model.positions)
+                idx = np.arange(nv, dtype=np.uint32).reshape(-1, 3)
+                md = MeshData(positions=model.positions.astype(F32), indices=idx)
+                if model.normals is not None:
+                    md.normals, md.normal_indices = model.normals.astype(F32), idx.copy()
+                if model.tex_coords is not None:
+                    uv = model.tex_coords.astype(F32).copy()
+                    uv[:, 1] = F32(1.0) - uv[:, 1]        # flip y (src/scene.rs:871)
+                    md.uvs, md.uv_indices = uv, idx.copy()
+                self.meshes.append(md)
+                item = Shape(RR_ITEM_MESH, model.name, material_id)
+                item.mesh = len(self.meshes) - 1
+                item.id = object_id
+                loaded.append(object_id)
+                self.items.append(item)
         return loaded
 
     # ---- defaults (src/scene.rs:1386-1401, :1426-1562) ------------------------------------

@@ -11,6 +11,7 @@ and bench.py read these files only.
   monkey.npz      scene/monkey.json   (BASELINE config C2)
   kbert.npz       scene/kbert.json    (spot light, flat shading, two meshes, one base texture)
   earth_room.npz  scene/earth_in_room.json if loadable (textured sphere inside planes)
+  monkey_glb.npz  scene/models/monkey/monkey.glb through the glTF path (two glTF lights, glTF camera, textured plane)
 Synthetic stand-ins for C3-C5 (assets absent offline) are built from
 these by rustray_amd/synthetic.py at run time.
 """
@@ -82,3 +83,5 @@ def export_assets():
 
 if __name__ == "__main__":
     export_assets()
+    # glTF path (src/scene.rs:722-1124): the only .glb that ships inside the reference
+    export("monkey_glb", "scene/models/monkey/monkey.glb", 1280, 720)

@@ -33,6 +33,7 @@ SMALL = [  # scene, w, h, spp, mc, seed
     ("earth_room", 160, 90, 2, True, 2),       # 5 lights, textured sphere, planes
     ("spheres_room", 160, 90, 2, True, 3),
     ("monkey_room", 128, 72, 2, True, 4),
+    ("monkey_glb", 160, 90, 3, True, 6),       # glTF path: de-indexed world-space mesh, glTF lights and camera, roughness jitter
 ]
 
 

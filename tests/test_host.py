@@ -128,3 +128,28 @@ def test_synthetic_scenes_are_deterministic_and_sized():
     assert m.texture[0] >= 0 and m.texture[3] >= 0 and m.texture[5] >= 0 and m.texture[6] >= 0
     lo = synthetic.lotus_syn(grid=4)
     assert lo.meta["config"]["aperture_size"] == 16.0 and lo.meta["config"]["focal_length"] == 20.0
+
+
+@needs_reference
+def test_gltf_loader_semantics():
+    """monkey.glb through the glTF path (reference src/scene.rs:722-978)."""
+    from rustray_amd.scene import load_scene as load_ref
+    sc = load_ref("scene/models/monkey/monkey.glb", 320, 180, root=REF)
+    fs = sc.flatten()
+    assert [it.id for it in fs.items] == [3, 5]                 # lights take ids 1, 2; then (object, material) pairs
+    assert len(fs.meshes[0].indices) == 15744 and len(fs.meshes[0].positions) == 3 * 15744   # de-indexed (:853-892)
+    assert (fs.meshes[0].indices.reshape(-1) == np.arange(3 * 15744)).all()
+    assert len(fs.lights) == 2 and fs.lights[0].intensity == 100.0 and fs.lights[1].intensity == 500.0   # point: intensity / 10 (:747)
+    m = fs.materials[fs.items[0].material]
+    assert abs(m.base_color[2] - 0.8) < 1e-6 and m.reflectivity == 0.0
+    assert abs(m.roughness - 0.4 / (2 * math.pi)) < 1e-6           # (1/pi/2) * roughness_factor (:915)
+    assert all(abs(s - 0.8 * b) < 1e-6 for s, b in zip(m.specular_color, m.base_color))
+    assert abs(sc.cam.fov - 0.39959648) < 1e-6 and not sc.cam.is_default_cam()
+    # world-space vertices: the node scale 3.024 is baked in, item transforms stay identity
+    obj = load_ref("scene/models/monkey/monkey.obj", 64, 64, root=REF).flatten()
+    assert np.allclose(fs.meshes[0].positions.max(0), obj.meshes[0].positions.max(0), rtol=1e-4)
+    assert np.array_equal(fs.items[0].trans, np.eye(4, dtype=np.float32))
+    uv = fs.meshes[1].uvs
+    assert uv.min() >= -1e-6 and uv.max() <= 1.0 + 1e-6            # v flipped to 1 - v (:871)
+    g = load_scene("monkey_glb")
+    assert len(g.items) == 2 and np.array_equal(g.meshes[0].positions, fs.meshes[0].positions)
