@@ -101,6 +101,7 @@ class Scene:
         self._mesh_by_key: Dict[str, int] = {}
         # RaytracingConfig fields a JSON "config" block may override (src/scene.rs:180-198)
         self.raytracing_config: Dict[str, object] = {}
+        self.animation_json: Optional[dict] = None   # the scene file's `animation` block (src/scene.rs:549-628)
         self.name = ""
 
     # ---- ids ---------------------------------------------------------------
@@ -174,6 +175,8 @@ class Scene:
             if config.get("fog_color") is not None:
                 fc = config["fog_color"]
                 self.raytracing_config["fog_color"] = (_f32(fc["r"]), _f32(fc["g"]), _f32(fc["b"]))
+        if data.get("animation"):
+            self.animation_json = data["animation"]
         camera = data.get("camera")
         if camera:
             self.cam.eye_pos = np.asarray(self._xyz(camera, "pos", (0.0, 0.0, 0.0)))

@@ -153,3 +153,25 @@ def test_gltf_loader_semantics():
     assert uv.min() >= -1e-6 and uv.max() <= 1.0 + 1e-6            # v flipped to 1 - v (:871)
     g = load_scene("monkey_glb")
     assert len(g.items) == 2 and np.array_equal(g.meshes[0].positions, fs.meshes[0].positions)
+
+
+def test_animation_mirror():
+    """Keyframe interpolation of reference src/animation.rs (the helmet turntable of scene/helmet.json:55-92)."""
+    from rustray_amd.animation import Animation
+    an = Animation.from_json({"fps": 25, "enabled": True, "keyframes": [
+        {"time": 0, "objects": [{"name": "helmet", "transformation": {"rotation": {"x": -25.0, "y": 15.0, "z": 0.0},
+                                                                      "scale": {"x": 1.25, "y": 1.25, "z": 1.25}, "translation": {"x": 0.3, "y": 0.2, "z": 0.0}}}]},
+        {"time": 6000, "objects": [{"name": "helmet", "transformation": {"rotation": {"x": -25.0, "y": 375.0, "z": 0.0},
+                                                                         "scale": {"x": 1.25, "y": 1.25, "z": 1.25}, "translation": {"x": 0.3, "y": 0.2, "z": 0.0}}}]}]})
+    assert an.has_animation() and an.get_frames_amount_to_render() == 150
+    first, last, f = an.get_keyframes_for_frame(75)
+    assert (first.time, last.time) == (0, 6000) and abs(f - 0.5) < 1e-12
+    m = an.get_trans_for_frame(75, "helmet")
+    # T * Rz * Ry * Rx * S with ry = 195 deg, rx = -25 deg, s = 1.25
+    ry, rx = math.radians(195.0), math.radians(-25.0)
+    assert abs(m[0, 0] - 1.25 * math.cos(ry)) < 1e-5 and abs(m[1, 1] - 1.25 * math.cos(rx)) < 1e-5
+    assert abs(m[0, 3] - 0.3) < 1e-6 and abs(m[1, 3] - 0.2) < 1e-6
+    assert an.get_trans_for_frame(75, "nobody") is None
+    assert not Animation.from_json({"fps": 25, "enabled": True, "keyframes": [{"time": 0, "objects": []}]}).has_animation()
+    back = Animation.from_meta(an.to_meta())
+    assert np.array_equal(back.get_trans_for_frame(10, "helmet"), an.get_trans_for_frame(10, "helmet"))
