@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile", default="32x8")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     args = ap.parse_args()
 
     import torch
@@ -106,10 +107,13 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    n_dev = torch.cuda.device_count()
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % max(n_dev, 1)   # rehearsal on fewer GPUs than ranks
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
 
     fs, cam, cfg = build_workload(args)
     tw, th = [int(v) for v in args.tile.split("x")]
@@ -120,7 +124,7 @@ def main():
 
     def step():
         parts = render_region_torch(ds, camc, cfg, tf, aux=False)
-        return tf.gather(parts, use_device_kernel=True)
+        return tf.gather(parts, use_device_kernel=True, via_cpu=(args.dist_backend == "gloo"))
 
     def fence():
         if world > 1:
@@ -142,8 +146,9 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     # MAX over ranks of the wall time; SUM over ranks of the work
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    work = torch.tensor([acc["primary_rays"], acc["secondary_rays"], acc["shadow_rays"], acc["shaded_hits"]], dtype=torch.float64, device="cuda")
+    rdev = "cpu" if args.dist_backend == "gloo" else "cuda"
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
+    work = torch.tensor([acc["primary_rays"], acc["secondary_rays"], acc["shadow_rays"], acc["shaded_hits"]], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(work, op=dist.ReduceOp.SUM)
@@ -185,10 +190,11 @@ def main():
             bytes_per_launch = bpr * n_closest_r0 / launches
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-            if os.path.exists(tpath):
+            import glob
+            tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+            if tpaths:   # PMC passes are separate rocprofv3 runs (tools/profile_round.sh); the newest committed summary is quoted
                 try:
-                    traffic = json.load(open(tpath)).get("k_trace_closest_bytes_per_launch")
+                    traffic = json.load(open(tpaths[-1])).get("k_trace_closest_bytes_per_launch")
                 except Exception:  # noqa: BLE001
                     traffic = None
             result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

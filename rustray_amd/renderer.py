@@ -159,20 +159,25 @@ class TiledFrame:
             self._index = torch.from_numpy(idx).to(device)
         return self._index
 
-    def gather(self, parts: dict, use_device_kernel: bool = False) -> Optional[dict]:
+    def gather(self, parts: dict, use_device_kernel: bool = False, via_cpu: bool = False) -> Optional[dict]:
+        """via_cpu: stage the compact buffers through host memory (for the gloo backend, which cannot gather
+        device tensors); the default gathers device tensors directly (backend "nccl" = RCCL over xGMI)."""
         import torch
         import torch.distributed as dist
         out = {}
         for key, t in parts.items():
             t = t.reshape(self.n_pixels(), -1)
             if self.world_size > 1:
+                dev = t.device
                 pad = torch.zeros((self.max_count, t.shape[1]), dtype=t.dtype, device=t.device)
                 pad[: t.shape[0]] = t
+                if via_cpu:
+                    pad = pad.cpu()
                 gl = [torch.empty_like(pad) for _ in range(self.world_size)] if self.rank == 0 else None
                 dist.gather(pad, gl, dst=0)
                 if self.rank != 0:
                     continue
-                cat = torch.cat([gl[r][: self.counts[r]] for r in range(self.world_size)], dim=0)
+                cat = torch.cat([gl[r][: self.counts[r]] for r in range(self.world_size)], dim=0).to(dev)
             else:
                 cat = t
             if use_device_kernel and cat.is_cuda:
