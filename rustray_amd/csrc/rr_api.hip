@@ -73,8 +73,6 @@ struct rr_scene {
     DevBuf items, nodes, tris, attrs, face_slot, materials, textures, texels, lights;
     DSceneView view{};
     std::vector<DItem> h_items;
-    std::vector<uint32_t> item_mesh; // mesh index per item (or ~0u)
-    std::vector<float> mesh_lo, mesh_hi; // unused placeholders for future refits
     uint32_t n_enabled_lights = 0;
     uint32_t tlas_node_capacity = 0;
     // frame state (grown on demand, reused across frames)
@@ -94,10 +92,11 @@ struct rr_scene {
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
     hipEvent_t frame_a = nullptr, frame_b = nullptr;
+    hipStream_t last_stream = nullptr; // frame state (queues, accumulators) is shared: frames on different streams are serialised
     uint32_t* h_count = nullptr; // pinned: level sizes read back between depth levels
 };
 
-static const uint32_t POOL_WORDS = 16384;
+static const uint32_t POOL_WORDS = 1u << 18; // per-batch counters (level sizes, fetch heads, shadow shard counts): 1 MB, zeroed per batch
 
 // ---------------------------------------------------------------------------
 // the reference's sub-sample table: StdRng::seed_from_u64(0) + shuffle + truncate
@@ -465,7 +464,6 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
 
     // ---- items
     s->h_items.resize(fs->n_items);
-    s->item_mesh.resize(fs->n_items);
     bool general_w = false;
     for (uint32_t i = 0; i < fs->n_items; i++) {
         const rr_item& it = fs->items[i];
@@ -487,12 +485,10 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         if (cache.reflection_only) f |= RR_IF_CACHE_REFL_ONLY;
         if (!(cache.alpha < 1.0f) && cache.backface_cullig) f |= RR_IF_SOLID_BASE; // the cache never has textures
         if (full.texture[RR_TEX_ALPHA] >= 0 && fs->textures[full.texture[RR_TEX_ALPHA]].width > 0) f |= RR_IF_OCCLUDER_ALPHA_TEX;
-        s->item_mesh[i] = ~0u;
         if (it.kind == RR_ITEM_SPHERE) {
             f |= RR_IF_SPHERE;
         } else {
             const MeshDev& m = md[it.mesh];
-            s->item_mesh[i] = (uint32_t)it.mesh;
             d.node_base = m.node_base; d.root = m.root; d.tri_base = m.tri_base; d.n_tris = m.n_tris;
             if (cache.smooth_shading && m.has_normals) f |= RR_IF_SMOOTH;
         }
@@ -581,7 +577,7 @@ extern "C" int rr_scene_update_transforms(rr_scene* s, const float* trans, const
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(s->items.p, s->h_items.data(), n * sizeof(DItem), hipMemcpyHostToDevice));
     s->view.general_w = general_w ? 1u : 0u;
-    if (s->view.use_tlas) {
+    {
         std::vector<DNode> tlas; int32_t root = 0;
         int rc = build_tlas(s, tmp, &tlas, &root);
         if (rc != RR_OK) return rc;
@@ -634,7 +630,9 @@ static void resolve_timers(rr_scene* s) {
 static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy,
                                 const rr_region* rg, const rr_frame* out, bool frame_layout, hipStream_t st, const volatile int* cancel) {
     HIP_TRY(hipSetDevice(s->device));
+    if (st != s->last_stream) { HIP_TRY(hipStreamSynchronize(s->last_stream)); s->last_stream = st; }
     const uint32_t W = cam->width, H = cam->height;
+    if ((uint64_t)W * H > (1ull << 30)) return fail(RR_ERR_UNSUPPORTED, "frame of %ux%u pixels", W, H);
     // ---- region map
     if (memcmp(&s->region_cached, rg, sizeof *rg) != 0 || s->region_w != W || s->region_h != H) {
         std::vector<uint32_t> order;
