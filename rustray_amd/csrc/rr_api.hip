@@ -500,7 +500,6 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     // candidate set, never the result.
     std::vector<DNode> tlas;
     int32_t tlas_root = (int32_t)0x80000000; // RR_SENTINEL: empty scene
-    uint32_t use_tlas = 1;
     if (fs->n_items >= 1) {
         std::vector<rr_item> items(fs->items, fs->items + fs->n_items);
         rc = build_tlas(s.get(), items, &tlas, &tlas_root);
@@ -528,7 +527,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     v.materials = s->materials.as<DMaterial>(); v.textures = s->textures.as<DTexture>(); v.texels = s->texels.as<uint32_t>();
     v.lights = s->lights.as<DLight>();
     v.n_items = fs->n_items; v.n_lights = fs->n_lights;
-    v.tlas_node_base = tlas_base; v.tlas_root = tlas_root; v.use_tlas = use_tlas; v.general_w = general_w ? 1u : 0u;
+    v.tlas_node_base = tlas_base; v.tlas_root = tlas_root; v.general_w = general_w ? 1u : 0u;
 
     HIP_TRY(s->pool.reserve(POOL_WORDS * 4));
     HIP_TRY(s->counters.reserve(RR_CNT_WORDS * 8));

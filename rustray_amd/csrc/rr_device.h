@@ -99,8 +99,8 @@ struct DSceneView {
     uint32_t n_items;
     uint32_t n_lights;
     uint32_t tlas_node_base; // global node index of the TLAS root's array
-    int32_t tlas_root;       // node index relative to tlas_node_base, leaf code, or 0 with use_tlas = 0
-    uint32_t use_tlas;
+    int32_t tlas_root;       // node index relative to tlas_node_base, a leaf code (one item), or RR_SENTINEL (empty scene)
+    uint32_t _pad0;
     uint32_t general_w;      // some trans_inv has a w row other than (0,0,0,1)
 };
 
