@@ -714,7 +714,10 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     B = std::max<uint64_t>(B, 4096);
     B = std::min<uint64_t>(B, total_primary);
     B = std::min<uint64_t>(B, 0x7fffffffull / std::max<uint64_t>(f_odd, 1));
-    if (B > npix) B = (B / npix) * npix; // whole sample slices when possible
+    // equal batches (a frame that needs 1.2 batches would otherwise end with a small, poorly filled one)
+    { const uint64_t nb = (total_primary + B - 1) / B; B = (total_primary + nb - 1) / nb; }
+    if (B > npix) B = ((B + npix - 1) / npix) * npix; // whole sample slices when possible
+    B = std::min<uint64_t>(B, total_primary);
     const uint64_t cap[2] = {B * f_odd, std::max<uint64_t>(B * f_even, 1)};
     const size_t elem[4] = {16, 16, 8, 16};
     for (int i = 0; i < 2; i++)

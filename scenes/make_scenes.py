@@ -39,7 +39,8 @@ if __name__ == "__main__":
     export("monkey", "scene/monkey.json", 800, 600)
     export("kbert", "scene/kbert.json", 1280, 720)
     for extra, path in (("earth_room", "scene/earth_in_room.json"), ("spheres_room", "scene/spheres_in_room.json"),
-                        ("monkey_room", "scene/monkey_in_room.json")):
+                        ("monkey_room", "scene/monkey_in_room.json"), ("kbert_room", "scene/kbert_in_room.json"),
+                        ("earth", "scene/earth.json"), ("floor", "scene/floor.json")):
         try:
             export(extra, path, 1280, 720)
         except Exception as e:  # noqa: BLE001

@@ -34,7 +34,10 @@ SMALL = [  # scene, w, h, spp, mc, seed
     ("earth_room", 160, 90, 2, True, 2),       # 5 lights, textured sphere, planes
     ("spheres_room", 160, 90, 2, True, 3),
     ("monkey_room", 128, 72, 2, True, 4),
-    ("monkey_glb", 160, 90, 3, True, 6),       # glTF path: de-indexed world-space mesh, glTF lights and camera, roughness jitter
+    ("monkey_glb", 160, 90, 3, True, 6),
+    ("kbert_room", 160, 90, 2, True, 8),       # two meshes inside a textured room, 5 lights
+    ("earth", 128, 128, 2, True, 9),           # sphere with base + specular + normal maps, auto camera
+    ("floor", 160, 90, 2, True, 10),           # one textured plane (bump map as normal map), 4 lights       # glTF path: de-indexed world-space mesh, glTF lights and camera, roughness jitter
 ]
 
 
