@@ -385,7 +385,9 @@ RR_DEV void shadow_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t dept
     float key, tmin;
     if (!aabb_cast2(it.bmin, it.bmax, lr, false, &key, &tmin)) return; // for_shadow forces solid = false
     if (key != key) return;
-    // An item whose box starts beyond the light cannot change the outcome: selected or not, the receiver is lit.
+    // An item whose box starts beyond the light can never be hit within the light distance; it is skipped in this
+    // pass.  It can still matter as a BLOCKER (hit, ordered before the occluder found here): trace_shadow_ray
+    // runs a second pass for exactly that case.
     if (tmin > limit) return;
     if (sel->found && !(key < sel->key || (key == sel->key && idx < sel->item))) return;
     bool any = false, within = false; float t = 0.0f; uint32_t face = 0u;
@@ -402,6 +404,55 @@ RR_DEV void shadow_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t dept
         }
     }
     if (any) { sel->found = true; sel->key = key; sel->item = idx; sel->within = within; sel->t = t; sel->face = face; }
+}
+
+// Second pass of a shadow query: is there an item whose box starts BEYOND the light (skipped above), ordered before
+// the selected occluder (sel), that is hit at all?  The reference tries candidates in bbox-distance order and the
+// first one that is hit decides (src/raytracing.rs:466-487); its hit lies beyond the light, so the receiver is lit.
+RR_DEV bool shadow_blocker_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t depth, float limit, const ShadowSel& sel,
+                                int* s_stack, int sp_base) {
+    const DItem& it = sc.items[idx];
+    const uint32_t flags = it.flags;
+    if (!item_passes(flags, true, depth)) return false;
+    LRay lr = inverse_ray(it, o, d, sc.general_w != 0u);
+    float key, tmin;
+    if (!aabb_cast2(it.bmin, it.bmax, lr, false, &key, &tmin)) return false;
+    if (key != key || !(tmin > limit)) return false;
+    if (!(key < sel.key || (key == sel.key && idx < sel.item))) return false;
+    if (flags & RR_IF_SPHERE) { float t; bool inside; return ray_ball(it.radius, lr, false, &t, &inside); }
+    if (it.n_tris == 0u) return false;
+    bool any = false, within = false;
+    blas_any(sc, it, lr, RR_FLT_MAX, s_stack, sp_base, &any, &within);
+    return any;
+}
+
+RR_DEV bool trace_shadow_blockers(const DSceneView& sc, f3 o, f3 d, uint32_t depth, float limit, const ShadowSel& sel, int* s_stack) {
+    const SlabRay sr = make_slab(o, d);
+    const DNode* nodes = sc.nodes + sc.tlas_node_base;
+    int sp = 0;
+    int cur = sc.tlas_root;
+    for (;;) {
+        if (cur >= 0) {
+            const DNode nd = nodes[cur];
+            const float bound = sel.key * 1.00001f + 1e-6f; // a blocker's box starts before the occluder's key
+            float e0, e1;
+            bool h0 = slab2(nd.n0.x, nd.n0.y, nd.n0.z, nd.n0.w, nd.n2.x, nd.n2.y, sr, bound, &e0);
+            bool h1 = slab2(nd.n1.x, nd.n1.y, nd.n1.z, nd.n1.w, nd.n2.z, nd.n2.w, sr, bound, &e1);
+            int c0 = __float_as_int(nd.n3.x), c1 = __float_as_int(nd.n3.y);
+            if (h0 && h1) { STK(sp) = c1; sp++; cur = c0; }
+            else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else { if (sp == 0) break; sp--; cur = STK(sp); }
+        } else {
+            uint32_t code = (uint32_t)~cur;
+            uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
+            for (uint32_t i = 0; i < count; i++)
+                if (shadow_blocker_item(sc, (int)(first + i), o, d, depth, limit, sel, s_stack, sp)) return true;
+            if (sp == 0) break;
+            sp--; cur = STK(sp);
+        }
+    }
+    return false;
 }
 
 RR_DEV void trace_shadow_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, float limit, int* s_stack, ShadowSel* sel) {
@@ -435,6 +486,9 @@ RR_DEV void trace_shadow_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, f
             sp--; cur = STK(sp);
         }
     }
+    // The occluder found has a hit within the light distance.  Only if its sort key lies beyond the light (its box
+    // contains the ray origin, so the key is the box EXIT distance) can an item that starts beyond the light precede it.
+    if (sel->found && sel->within && sel->key > limit && trace_shadow_blockers(sc, o, d, depth, limit, *sel, s_stack)) sel->within = false;
 }
 
 // ---------------------------------------------------------------------------

@@ -254,3 +254,56 @@ def test_animation_frames_match_oracle(hip, oracle):
             for it, t, ti in zip(fs.items, trans, inv):
                 it.trans, it.trans_inv = t, ti
             assert_parity(out, oracle.render(fs.c_struct(), cam, cfg, n_threads=16), f"frame {frame}")
+
+
+def _blocker_scene():
+    """Corner of the reference's shadow semantics (src/raytracing.rs:466-487, :886-892): candidates are tried in
+    bbox-distance order and the FIRST item that is hit decides.  Item Y (an occluder quad plus a far triangle that
+    stretches Y's box past the light, so the shadow origin lies INSIDE Y's box and Y's key is the box EXIT distance)
+    would shadow the floor, but the sphere X behind the light has a smaller key (its box entry), is hit beyond the
+    light and therefore makes the receiver lit."""
+    from rustray_amd.flat import FlatScene, Item, Light, Material, MeshData
+    from rustray_amd.scene import Scene
+    fs = FlatScene()
+
+    def add_mat(m):
+        fs.materials.append(m); fs.materials.append(Scene._cache_of(m))
+        return len(fs.materials) - 2, len(fs.materials) - 1
+    eye4 = np.eye(4, dtype=np.float32)
+    floor = MeshData(positions=np.asarray([[-20, 0, 20], [20, 0, 20], [20, 0, -20], [-20, 0, -20]], np.float32),
+                     indices=np.asarray([[0, 1, 2], [0, 2, 3]], np.uint32))
+    # Y: a 2x2 occluder at height 3 above the origin region, and a far sliver at height 40 that extends the box
+    ypos = np.asarray([[-1, 3, 1], [1, 3, 1], [1, 3, -1], [-1, 3, -1], [30, 40, 30], [31, 40, 30], [30, 40, 31],
+                       [-30, -1, -30], [-31, -1, -30], [-30, -1, -31]], np.float32)
+    ymesh = MeshData(positions=ypos, indices=np.asarray([[0, 1, 2], [0, 2, 3], [4, 5, 6], [7, 8, 9]], np.uint32))
+    fs.meshes = [floor, ymesh]
+    m0, c0 = add_mat(Material(base_color=(0.8, 0.8, 0.8)))
+    m1, c1 = add_mat(Material(base_color=(0.9, 0.2, 0.2)))
+    m2, c2 = add_mat(Material(base_color=(0.2, 0.9, 0.2)))
+    fs.items = [Item(kind=1, id=3, material=m0, material_cache=c0, mesh=0, trans=eye4.copy(), trans_inv=eye4.copy(),
+                     bbox_min=(-20, 0, -20), bbox_max=(20, 0, 20), name="floor"),
+                Item(kind=1, id=6, material=m1, material_cache=c1, mesh=1, trans=eye4.copy(), trans_inv=eye4.copy(),
+                     bbox_min=tuple(ypos.min(0)), bbox_max=tuple(ypos.max(0)), name="Y"),
+                Item(kind=0, id=9, material=m2, material_cache=c2, radius=2.0, name="X",
+                     trans=np.asarray([[1, 0, 0, 0], [0, 1, 0, 12], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32),
+                     trans_inv=np.asarray([[1, 0, 0, 0], [0, 1, 0, -12], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32),
+                     bbox_min=(-2, -2, -2), bbox_max=(2, 2, 2))]
+    fs.lights = [Light(pos=(0.0, 8.0, 0.0), color=(1.0, 1.0, 1.0), intensity=60.0, light_type=1)]
+    fs.meta = {"camera": dict(width=64, height=64, fov=float(np.float32(np.radians(60.0))), eye_pos=[0.0, 6.0, 9.0], up=[0.0, 1.0, 0.0],
+                              dir=[0.0, -0.6, -1.0], clipping_near=0.1, clipping_far=100.0)}
+    return fs
+
+
+def test_shadow_blocker_beyond_the_light(hip, oracle):
+    fs = _blocker_scene()
+    cam = camera_for(fs, 96, 96).c_struct()
+    cfg = make_config(samples=1, monte_carlo=False)
+    ref = oracle.render(fs.c_struct(), cam, cfg, n_threads=8)
+    # the semantics under test really occur: removing X darkens floor pixels under the occluder
+    fs2 = _blocker_scene(); fs2.items[2].visible = False
+    ref_without_x = oracle.render(fs2.c_struct(), cam, cfg, n_threads=8)
+    floor_px = ref["object_id"] == 3
+    assert (ref["rgba"][floor_px].astype(int).sum(-1) > ref_without_x["rgba"][floor_px].astype(int).sum(-1) + 30).sum() > 20
+    with hip.DeviceScene(fs, 0) as ds:
+        out = ds.render(cam, cfg)
+    assert_parity(out, ref, "blocker beyond the light")
