@@ -1,0 +1,120 @@
+"""Adversarial scenes for order-dependent and rarely taken paths of the reference's trace loop, GPU vs oracle."""
+import numpy as np
+import pytest
+
+from rustray_amd.flat import FlatScene, Item, Light, Material, MeshData, make_config
+from rustray_amd.scene import Scene
+from tests.helpers import camera_for
+from tests.test_gpu_parity import assert_parity
+
+pytestmark = pytest.mark.gpu
+EYE = np.eye(4, dtype=np.float32)
+
+
+def _mat(fs, m):
+    fs.materials.append(m); fs.materials.append(Scene._cache_of(m))
+    return len(fs.materials) - 2, len(fs.materials) - 1
+
+
+def _quad(y, half, uv=True):
+    p = np.asarray([[-half, y, half], [half, y, half], [half, y, -half], [-half, y, -half]], np.float32)
+    md = MeshData(positions=p, indices=np.asarray([[0, 1, 2], [0, 2, 3]], np.uint32))
+    if uv:
+        md.uvs = np.asarray([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+        md.uv_indices = np.asarray([[0, 1, 2], [0, 2, 3]], np.uint32)
+    return md
+
+
+def _mesh_item(fs, mesh, mat, idn, name, bbox=None, trans=None, trans_inv=None):
+    p = fs.meshes[mesh].positions
+    mi, ci = _mat(fs, mat)
+    lo, hi = (tuple(p.min(0)), tuple(p.max(0))) if bbox is None else bbox
+    fs.items.append(Item(kind=1, id=idn, material=mi, material_cache=ci, mesh=mesh, trans=(EYE if trans is None else trans).copy(),
+                         trans_inv=(EYE if trans_inv is None else trans_inv).copy(), bbox_min=lo, bbox_max=hi, name=name))
+
+
+def _cam(fs, eye=(0.0, 6.0, 9.0), direction=(0.0, -0.6, -1.0), fov=60.0):
+    fs.meta = {"camera": dict(width=64, height=64, fov=float(np.float32(np.radians(fov))), eye_pos=list(eye), up=[0.0, 1.0, 0.0],
+                              dir=list(direction), clipping_near=0.1, clipping_far=100.0)}
+
+
+def _check(hip, oracle, fs, w=96, h=96, **cfg):
+    cam = camera_for(fs, w, h).c_struct()
+    c = make_config(**({"samples": 2, "monte_carlo": True, "seed": 3} | cfg))
+    with hip.DeviceScene(fs, 0) as ds:
+        out = ds.render(cam, c)
+    ref = oracle.render(fs.c_struct(), cam, c, n_threads=8)
+    assert_parity(out, ref)
+    return out, ref
+
+
+def test_equal_toi_goes_to_the_smaller_bbox_distance_then_index(hip, oracle):
+    """Two items share ONE mesh (bit-equal toi).  The stable sort by bbox distance + strict `<` of the reference
+    (src/raytracing.rs:466-476) gives the hit to the item with the smaller bbox distance, index breaking ties."""
+    fs = FlatScene()
+    fs.meshes = [_quad(0.0, 5.0)]
+    _mesh_item(fs, 0, Material(base_color=(1.0, 0.1, 0.1)), 3, "red")
+    _mesh_item(fs, 0, Material(base_color=(0.1, 1.0, 0.1)), 6, "green")
+    fs.lights = [Light(pos=(0.0, 8.0, 0.0), intensity=80.0)]
+    _cam(fs)
+    out, _ = _check(hip, oracle, fs)
+    assert set(np.unique(out["object_id"])) == {0, 3}                       # same key: the lower index wins
+    fs.items[1].bbox_min, fs.items[1].bbox_max = (-5.0, -1.0, -5.0), (5.0, 1.0, 5.0)   # a thicker declared box is entered earlier
+    out, _ = _check(hip, oracle, fs)
+    assert set(np.unique(out["object_id"])) == {0, 6}
+
+
+def test_alpha_textured_occluder_and_short_uv_lists(hip, oracle):
+    """Occluder alpha maps (src/raytracing.rs:894-913: receiver's alpha, receiver's get_uv, occluder's face id) and
+    Mesh::get_uv's bounds test for faces without uv indices (src/shape/mesh.rs:116-120)."""
+    fs = FlatScene()
+    rng = np.random.default_rng(4)
+    alpha = np.zeros((16, 16, 4), np.uint8); alpha[..., :3] = (rng.integers(0, 2, (16, 16, 1)) * 255).astype(np.uint8); alpha[..., 3] = 255
+    base = np.full((8, 8, 4), 255, np.uint8); base[::2, ::2, :3] = 60
+    fs.textures = [alpha, base]
+    floor, cover = _quad(0.0, 10.0), _quad(3.0, 2.5)
+    cover.uv_indices = cover.uv_indices[:1]                                  # second face has no uv indices -> uv (0,0)
+    fs.meshes = [floor, cover]
+    fm = Material(base_color=(0.9, 0.9, 0.9)); fm.texture[0] = 1
+    _mesh_item(fs, 0, fm, 3, "floor")
+    cm = Material(base_color=(0.2, 0.3, 0.9), alpha=0.7, refraction_index=1.2); cm.texture[4] = 0; cm.texture[0] = 1
+    _mesh_item(fs, 1, cm, 6, "cover")
+    fs.lights = [Light(pos=(1.0, 9.0, 2.0), intensity=90.0), Light(pos=(-3.0, 6.0, -1.0), color=(1.0, 0.6, 0.3), intensity=50.0)]
+    _cam(fs)
+    for nearest in (False, True):
+        fs.materials[fs.items[1].material].texture_filtering_nearest = nearest
+        _check(hip, oracle, fs, samples=3)
+
+
+def test_camera_inside_solid_and_hollow_spheres(hip, oracle):
+    """Ball::cast_local_ray from inside: a solid ball answers toi = 0, a non-solid one its far side."""
+    for alpha, cull in ((1.0, True), (1.0, False), (0.6, True)):
+        fs = FlatScene()
+        m = Material(base_color=(0.7, 0.8, 0.9), alpha=alpha, backface_cullig=cull, reflectivity=0.2, refraction_index=1.3)
+        mi, ci = _mat(fs, m)
+        fs.items = [Item(kind=0, id=3, material=mi, material_cache=ci, radius=6.0, bbox_min=(-6.0,) * 3, bbox_max=(6.0,) * 3, name="shell")]
+        m2 = Material(base_color=(0.9, 0.4, 0.1))
+        mi2, ci2 = _mat(fs, m2)
+        t = EYE.copy(); t[:3, 3] = (0.5, -0.5, -3.0); ti = EYE.copy(); ti[:3, 3] = (-0.5, 0.5, 3.0)
+        fs.items.append(Item(kind=0, id=6, material=mi2, material_cache=ci2, radius=1.0, trans=t, trans_inv=ti, bbox_min=(-1.0,) * 3, bbox_max=(1.0,) * 3, name="ball"))
+        fs.lights = [Light(pos=(1.0, 2.0, 1.0), intensity=30.0)]
+        _cam(fs, eye=(0.0, 0.0, 0.0), direction=(0.0, 0.0, -1.0), fov=80.0)
+        _check(hip, oracle, fs, samples=2)
+
+
+def test_projective_inverse_and_non_uniform_scale(hip, oracle):
+    """get_inverse_ray divides the transformed origin by w (Point3::from_homogeneous, src/shape/mod.rs:757-760): a w row
+    other than (0,0,0,1) must be honoured; normals use `trans`, not its inverse transpose (Appendix A 13)."""
+    fs = FlatScene()
+    fs.meshes = [_quad(0.0, 4.0)]
+    _mesh_item(fs, 0, Material(base_color=(0.8, 0.8, 0.8), reflectivity=0.3), 3, "floor")
+    s = np.diag(np.asarray([1.5, 0.6, 1.0, 1.0], np.float32)); s[:3, 3] = (0.0, 1.5, -1.0)
+    si = np.linalg.inv(s.astype(np.float64)).astype(np.float32)
+    si[3, :] = (0.0, 0.0, 0.0, 2.0)                                          # homogeneous scale: origin' = (M x) / 2
+    si[:3, :] *= 2.0                                                        # ... compensated in the first three rows
+    m = Material(base_color=(0.2, 0.7, 0.3), alpha=0.5, refraction_index=1.4, reflectivity=0.3)
+    mi, ci = _mat(fs, m)
+    fs.items.append(Item(kind=0, id=6, material=mi, material_cache=ci, radius=1.0, trans=s, trans_inv=si, bbox_min=(-1.0,) * 3, bbox_max=(1.0,) * 3, name="ellipsoid"))
+    fs.lights = [Light(pos=(2.0, 7.0, 3.0), intensity=70.0)]
+    _cam(fs, eye=(0.0, 3.0, 6.0), direction=(0.0, -0.35, -1.0))
+    _check(hip, oracle, fs, samples=2)
