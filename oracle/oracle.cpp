@@ -667,7 +667,14 @@ static bool trace(const OScene& sc, const Ray& ray, bool stop_on_first_hit, bool
         }
     }
     if (hits.empty()) return false;
-    std::stable_sort(hits.begin(), hits.end(), [](const Cand& a, const Cand& b) { return a.dist < b.dist; });
+    // stable sort by bbox distance (src/raytracing.rs:466); insertion sort: candidate lists are short and
+    // std::stable_sort's temporary buffer would put a malloc into every trace call
+    for (size_t i = 1; i < hits.size(); i++) {
+        Cand c = hits[i];
+        size_t j = i;
+        while (j > 0 && c.dist < hits[j - 1].dist) { hits[j] = hits[j - 1]; j--; }
+        hits[j] = c;
+    }
     bool have = false;
     TraceHit best{};
     for (const Cand& c : hits) {
@@ -1278,7 +1285,9 @@ static int render_prepared(const OScene& sc, const rr_camera* cam, const rr_conf
     std::vector<rro_counters> tcnt(n_threads);
     std::memset(tcnt.data(), 0, sizeof(rro_counters) * n_threads);
     auto worker = [&](int tid) {
-        tl_cnt = counters ? &tcnt[tid] : nullptr;
+        rro_counters local;              // on this thread's stack: adjacent vector slots would share cache lines
+        std::memset(&local, 0, sizeof local);
+        tl_cnt = counters ? &local : nullptr;
         for (;;) {
             size_t i = next.fetch_add(1);
             if (i >= cells.size()) break;
@@ -1295,6 +1304,7 @@ static int render_prepared(const OScene& sc, const rr_camera* cam, const rr_conf
                 }
         }
         tl_cnt = nullptr;
+        tcnt[tid] = local;
     };
     if (n_threads == 1) worker(0);
     else {
