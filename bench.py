@@ -55,12 +55,36 @@ def build_workload(args):
     return fs, cam, cfg
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: the smallest of the online count, the affinity mask and the cgroup quota
+    (a GPU box shows all host CPUs but grants a share of them)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def cpu_baseline(fs, cam, args):
     """Oracle (C++ restatement of the reference algorithm, oracle/) on the host cores, bounded sample:
     the same frame at `cpu_spp` samples per pixel.  Also yields the algorithmic-byte model."""
     from oracle import binding as ob
     from rustray_amd.flat import make_config
-    threads = max(1, (os.cpu_count() or 1) - 2)  # num_cpus - 2, reference src/renderer.rs:67-71
+    threads = max(1, usable_cpus() - 2)  # num_cpus - 2, reference src/renderer.rs:67-71
     cfg = make_config(samples=args.cpu_spp, monte_carlo=bool(args.monte_carlo), seed=0, max_recursion=6)
     cs = fs.c_struct()
     t0 = time.time()
