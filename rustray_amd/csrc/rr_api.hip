@@ -70,7 +70,7 @@ struct rr_scene {
     int n_cus = 256;
     std::mutex mu;
     // scene data
-    DevBuf items, nodes, tris, attrs, face_slot, materials, textures, texels, lights;
+    DevBuf items, nodes, nodes4, tris, attrs, face_slot, materials, textures, texels, lights;
     DSceneView view{};
     std::vector<DItem> h_items;
     uint32_t n_enabled_lights = 0;
@@ -401,9 +401,10 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     if (!dl.empty()) HIP_TRY(hipMemcpy(s->lights.p, dl.data(), dl.size() * sizeof(DLight), hipMemcpyHostToDevice));
 
     // ---- meshes: one BLAS per mesh, shared by every item that names it
-    struct MeshDev { uint32_t node_base, tri_base, n_tris; int32_t root; bool has_normals; };
+    struct MeshDev { uint32_t node_base, tri_base, n_tris; int32_t root; uint32_t node_base4; int32_t root4; bool has_normals; };
     std::vector<MeshDev> md(fs->n_meshes);
     std::vector<DNode> all_nodes;
+    std::vector<DNode4> all_nodes4;
     std::vector<DTri> all_tris;
     std::vector<DTriAttr> all_attrs;
     std::vector<uint32_t> all_face_slot;
@@ -429,6 +430,14 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         md[mi].root = r.root;
         md[mi].has_normals = m.n_normals > 0 && m.n_normal_faces > 0;
         all_nodes.insert(all_nodes.end(), r.nodes.begin(), r.nodes.end());
+#if RR_BVH4
+        int pending = 0;
+        md[mi].node_base4 = (uint32_t)all_nodes4.size();
+        md[mi].root4 = rr::collapse_bvh4(r, RR_BLAS_MAX_DEPTH, &all_nodes4, &pending);
+        if (pending > RR_BLAS_MAX_DEPTH) return fail(RR_ERR_UNSUPPORTED, "mesh %u: BVH4 stack bound exceeded", mi);
+#else
+        md[mi].node_base4 = 0; md[mi].root4 = r.root;
+#endif
         size_t fs_base = all_face_slot.size();
         all_face_slot.resize(fs_base + nt);
         for (uint32_t slot = 0; slot < nt; slot++) {
@@ -490,6 +499,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         } else {
             const MeshDev& m = md[it.mesh];
             d.node_base = m.node_base; d.root = m.root; d.tri_base = m.tri_base; d.n_tris = m.n_tris;
+            d.node_base4 = m.node_base4; d.root4 = m.root4;
             if (cache.smooth_shading && m.has_normals) f |= RR_IF_SMOOTH;
         }
         d.flags = f;
@@ -516,13 +526,14 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         return bytes ? hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
     };
     HIP_TRY(upload(s->nodes, all_nodes.data(), all_nodes.size() * sizeof(DNode)));
+    HIP_TRY(upload(s->nodes4, all_nodes4.data(), all_nodes4.size() * sizeof(DNode4)));
     HIP_TRY(upload(s->tris, all_tris.data(), all_tris.size() * sizeof(DTri)));
     HIP_TRY(upload(s->attrs, all_attrs.data(), all_attrs.size() * sizeof(DTriAttr)));
     HIP_TRY(upload(s->face_slot, all_face_slot.data(), all_face_slot.size() * 4));
     HIP_TRY(upload(s->items, s->h_items.data(), s->h_items.size() * sizeof(DItem)));
 
     DSceneView& v = s->view;
-    v.items = s->items.as<DItem>(); v.nodes = s->nodes.as<DNode>(); v.tris = s->tris.as<DTri>(); v.attrs = s->attrs.as<DTriAttr>();
+    v.items = s->items.as<DItem>(); v.nodes = s->nodes.as<DNode>(); v.nodes4 = s->nodes4.as<DNode4>(); v.tris = s->tris.as<DTri>(); v.attrs = s->attrs.as<DTriAttr>();
     v.face_slot = s->face_slot.as<uint32_t>();
     v.materials = s->materials.as<DMaterial>(); v.textures = s->textures.as<DTexture>(); v.texels = s->texels.as<uint32_t>();
     v.lights = s->lights.as<DLight>();

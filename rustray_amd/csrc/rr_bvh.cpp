@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 
 namespace rr {
 
@@ -151,6 +152,79 @@ struct Builder {
 };
 
 } // namespace
+
+namespace {
+struct Box4 { float lo[3], hi[3]; };
+inline int32_t child_of(const DNode& n, int k) { int32_t c; std::memcpy(&c, k == 0 ? &n.n3.x : &n.n3.y, 4); return c; }
+inline Box4 box_of(const DNode& n, int k) {
+    Box4 b;
+    if (k == 0) { b.lo[0] = n.n0.x; b.hi[0] = n.n0.y; b.lo[1] = n.n0.z; b.hi[1] = n.n0.w; b.lo[2] = n.n2.x; b.hi[2] = n.n2.y; }
+    else { b.lo[0] = n.n1.x; b.hi[0] = n.n1.y; b.lo[1] = n.n1.z; b.hi[1] = n.n1.w; b.lo[2] = n.n2.z; b.hi[2] = n.n2.w; }
+    return b;
+}
+struct Collapse {
+    const BvhResult& b2;
+    std::vector<int> height; // BVH2 inner levels below (and including) each node
+    std::vector<DNode4>* out;
+    int limit, max_pending;
+    int h_of(int32_t code) const { return code < 0 ? 0 : height[code]; }
+    int fill_heights(int32_t n) {
+        if (n < 0) return 0;
+        int h = 1 + std::max(fill_heights(child_of(b2.nodes[n], 0)), fill_heights(child_of(b2.nodes[n], 1)));
+        height[n] = h;
+        return h;
+    }
+    // A walk that is `pending` entries deep when it reaches n2 must still fit the stack below it.  A node adopts its
+    // grandchildren only when every resulting subtree keeps that promise in the worst case (binary nodes all the way
+    // down cost one entry per BVH2 level), so trees up to `limit` BVH2 levels stay traversable with `limit` entries.
+    int32_t rec(int32_t n2, int pending) {
+        if (n2 < 0) { max_pending = std::max(max_pending, pending); return n2; }
+        struct Slot { int32_t code; Box4 box; };
+        const int32_t ch[2] = {child_of(b2.nodes[n2], 0), child_of(b2.nodes[n2], 1)};
+        Slot slots[4]; int ns = 0;
+        // which children to open: both, one, or none
+        static const int plans[4][2] = {{1, 1}, {1, 0}, {0, 1}, {0, 0}};
+        for (int p = 0; p < 4; p++) {
+            ns = 0;
+            bool ok = true;
+            for (int k = 0; k < 2; k++) {
+                if (plans[p][k] && ch[k] >= 0) {
+                    for (int g = 0; g < 2; g++) { slots[ns].code = child_of(b2.nodes[ch[k]], g); slots[ns].box = box_of(b2.nodes[ch[k]], g); ns++; }
+                } else { slots[ns].code = ch[k]; slots[ns].box = box_of(b2.nodes[n2], k); ns++; }
+            }
+            for (int s = 0; s < ns; s++) ok = ok && (pending + (ns - 1) + h_of(slots[s].code) <= limit);
+            if (ok) break;
+        }
+        const int32_t idx = (int32_t)out->size();
+        out->emplace_back();
+        int32_t codes[4];
+        for (int s = 0; s < ns; s++) codes[s] = rec(slots[s].code, pending + (ns - 1));
+        const float inf = std::numeric_limits<float>::infinity();
+        float v[7][4];
+        for (int s = 0; s < 4; s++) {
+            const bool used = s < ns;
+            // an unused slot is a point at +infinity: its entry distance is +inf or its exit -inf, never a hit
+            for (int a = 0; a < 3; a++) { v[2 * a][s] = used ? slots[s].box.lo[a] : inf; v[2 * a + 1][s] = used ? slots[s].box.hi[a] : inf; }
+            const int32_t code = used ? codes[s] : (int32_t)0x80000000;
+            std::memcpy(&v[6][s], &code, 4);
+        }
+        DNode4& nd = (*out)[idx];
+        for (int r = 0; r < 7; r++) nd.q[r] = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+        nd.q[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return idx;
+    }
+};
+} // namespace
+
+int32_t collapse_bvh4(const BvhResult& b2, int limit, std::vector<DNode4>* out, int* max_pending) {
+    std::vector<DNode4> local; // child indices are relative to the first node of this tree, like the BVH2 form
+    Collapse c{b2, std::vector<int>(b2.nodes.size(), 0), &local, limit, 0};
+    c.fill_heights(b2.root);
+    const int32_t root = c.rec(b2.root, 0);
+    out->insert(out->end(), local.begin(), local.end());
+    *max_pending = c.max_pending;
+    return root;
+}
 
 bool build_bvh(const float* boxes_lo, const float* boxes_hi, uint32_t n, uint32_t max_leaf, int max_depth, BvhResult* out) {
     Builder b;

@@ -15,6 +15,11 @@
 // child <  0: leaf, ~child = first | (count-1) << 28  (first relative to the prim base)
 struct DNode { float4 n0, n1, n2, n3; };
 
+// BVH4 node for the per-mesh trees, 128 B: four child boxes in SoA form and four child codes.
+//   q0 = lo.x[0..3]  q1 = hi.x[0..3]  q2 = lo.y  q3 = hi.y  q4 = lo.z  q5 = hi.z  q6 = child codes (int bits)  q7 unused
+// An unused slot has an inverted box (lo = +FLT_MAX, hi = -FLT_MAX), which no ray enters.
+struct DNode4 { float4 q[8]; };
+
 #define RR_LEAF_FIRST(code) ((uint32_t)(code) & 0x0fffffffu)
 #define RR_LEAF_COUNT(code) ((((uint32_t)(code)) >> 28) + 1u)
 #define RR_MAX_LEAF_TRIS 4
@@ -63,7 +68,8 @@ struct DItem {
     int32_t root;        // BLAS root: node index relative to node_base, or leaf code
     uint32_t tri_base;   // first DTri / DTriAttr of the mesh
     uint32_t n_tris;
-    uint32_t _pad[2];
+    uint32_t node_base4; // BVH4 form of the same tree
+    int32_t root4;
 };
 
 // 96 B material record
@@ -88,7 +94,8 @@ struct DLight {
 
 struct DSceneView {
     const DItem* items;
-    const DNode* nodes;     // all BLAS nodes, then the TLAS nodes
+    const DNode* nodes;     // all BLAS nodes (BVH2 build), then the TLAS nodes
+    const DNode4* nodes4;   // per-mesh trees collapsed to BVH4 (RR_BVH4 builds); DItem::node_base4 / root4 index it
     const DTri* tris;
     const DTriAttr* attrs;
     const uint32_t* face_slot; // per mesh triangle: original face index -> leaf-order slot

@@ -166,6 +166,10 @@ RR_DEV bool ray_ball(float radius, const LRay& ray, bool solid, float* toi_out, 
     }
 #define RR_SENTINEL ((int)0x80000000) // top-level root of an empty scene
 
+#ifndef RR_BVH4
+#define RR_BVH4 1
+#endif
+
 // The traversal's own box test is NOT part of the parity contract (only the exact primitive tests decide
 // hits), so its reciprocal is the hardware approximation.  The subtraction stays in front of the multiply:
 // the fused form plane * inv - o * inv cancels catastrophically when the origin sits within the shadow bias
@@ -192,6 +196,42 @@ RR_DEV bool slab2(float lox, float hix, float loy, float hiy, float loz, float h
     return tn_c <= tf * 1.000004f && tn_c <= bound;
 }
 
+#if RR_BVH4
+// One BVH4 inner-node step: four slab tests, a five-exchange sorting network on (entry, child), the three
+// farther children written far-to-near with the stack pointer advanced past the ones that were hit (a missed
+// child sorts last and its slot is overwritten), and the nearest taken directly.  Single branch, like the BVH2 step.
+#define RR_CSWAP(ka, ca, kb, cb) { const bool s_ = kb < ka; const float tk_ = s_ ? ka : kb; const int tc_ = s_ ? ca : cb; \
+                                   ka = s_ ? kb : ka; ca = s_ ? cb : ca; kb = tk_; cb = tc_; }
+#define RR_NODE4_STEP(nodes4, sr, bound)                                                                       \
+    {                                                                                                          \
+        const DNode4* np_ = (nodes4) + cur;                                                                    \
+        const float4 lx = np_->q[0], hx = np_->q[1], ly = np_->q[2], hy = np_->q[3], lz = np_->q[4], hz = np_->q[5], cc = np_->q[6]; \
+        float k0, k1, k2, k3;                                                                                  \
+        const bool h0 = slab2(lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, sr, bound, &k0);                             \
+        const bool h1 = slab2(lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, sr, bound, &k1);                             \
+        const bool h2 = slab2(lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, sr, bound, &k2);                             \
+        const bool h3 = slab2(lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, sr, bound, &k3);                             \
+        const float inf_ = __builtin_inff();                                                                   \
+        k0 = h0 ? k0 : inf_; k1 = h1 ? k1 : inf_; k2 = h2 ? k2 : inf_; k3 = h3 ? k3 : inf_;                    \
+        int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w); \
+        RR_CSWAP(k0, c0, k1, c1) RR_CSWAP(k2, c2, k3, c3) RR_CSWAP(k0, c0, k2, c2) RR_CSWAP(k1, c1, k3, c3) RR_CSWAP(k1, c1, k2, c2) \
+        STK(sp) = c3; sp += (k3 < inf_) ? 1 : 0;                                                               \
+        STK(sp) = c2; sp += (k2 < inf_) ? 1 : 0;                                                               \
+        STK(sp) = c1; sp += (k1 < inf_) ? 1 : 0;                                                               \
+        if (k0 < inf_) cur = c0;                                                                               \
+        else { sp--; cur = STK(sp); }                                                                          \
+    }
+#define RR_BLAS_NODES(sc, it) ((sc).nodes4 + (it).node_base4)
+#define RR_BLAS_ROOT(it) ((it).root4)
+#define RR_BLAS_STEP(nodes, sr, bound) RR_NODE4_STEP(nodes, sr, bound)
+typedef DNode4 BlasNode;
+#else
+#define RR_BLAS_NODES(sc, it) ((sc).nodes + (it).node_base)
+#define RR_BLAS_ROOT(it) ((it).root)
+#define RR_BLAS_STEP(nodes, sr, bound) RR_NODE_STEP(nodes, sr, bound)
+typedef DNode BlasNode;
+#endif
+
 // Nearest triangle of one mesh (TriMesh::cast_local_ray_and_get_normal,
 // reference src/shape/mesh.rs:67).  Ties at bit-equal toi go to the lowest
 // ORIGINAL face index.  `gbound`: hits beyond it cannot win upstream.
@@ -202,14 +242,14 @@ RR_DEV void blas_closest(const DSceneView& sc, const DItem& it, const LRay& ray,
                          int* s_stack, int sp_base, TriBest* out) {
     TriBest best; best.found = false; best.t = RR_FLT_MAX; best.slot = 0; best.face = 0xffffffffu; best.side = 0u;
     const SlabRay sr = make_slab(ray.o, ray.d);
-    const DNode* nodes = sc.nodes + it.node_base;
+    const BlasNode* nodes = RR_BLAS_NODES(sc, it);
     const DTri* tris = sc.tris + it.tri_base;
     int sp = sp_base;
     STK(sp) = RR_SENTINEL; sp++;
-    int cur = it.root;
+    int cur = RR_BLAS_ROOT(it);
     while (cur != RR_SENTINEL) {
         if (cur >= 0) {
-            RR_NODE_STEP(nodes, sr, fminf(gbound, best.t))
+            RR_BLAS_STEP(nodes, sr, fminf(gbound, best.t))
         } else {
             const uint32_t code = (uint32_t)~cur;
             const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
@@ -236,15 +276,15 @@ RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, flo
                      int* s_stack, int sp_base, bool* found_any, bool* found_within) {
     bool any = false, within = false;
     const SlabRay sr = make_slab(ray.o, ray.d);
-    const DNode* nodes = sc.nodes + it.node_base;
+    const BlasNode* nodes = RR_BLAS_NODES(sc, it);
     const DTri* tris = sc.tris + it.tri_base;
     int sp = sp_base;
     STK(sp) = RR_SENTINEL; sp++;
-    int cur = it.root;
+    int cur = RR_BLAS_ROOT(it);
     while (cur != RR_SENTINEL) {
         if (cur >= 0) {
             // until some hit is known every box matters; afterwards only boxes that can still hold a hit within the limit
-            RR_NODE_STEP(nodes, sr, any ? limit : RR_FLT_MAX)
+            RR_BLAS_STEP(nodes, sr, any ? limit : RR_FLT_MAX)
         } else {
             const uint32_t code = (uint32_t)~cur;
             const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);

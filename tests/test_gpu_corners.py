@@ -118,3 +118,24 @@ def test_projective_inverse_and_non_uniform_scale(hip, oracle):
     fs.lights = [Light(pos=(2.0, 7.0, 3.0), intensity=70.0)]
     _cam(fs, eye=(0.0, 3.0, 6.0), direction=(0.0, -0.35, -1.0))
     _check(hip, oracle, fs, samples=2)
+
+
+def test_deep_mesh_tree_keeps_within_the_traversal_stack(hip, oracle):
+    """A geometric progression of nested triangles makes SAH peel one primitive per level, so the per-mesh tree reaches
+    the builder's depth limit; the 4-wide collapse must then stay binary where the LDS stack budget is tight
+    (rustray_amd/csrc/rr_bvh.cpp) and every triangle must remain reachable."""
+    n = 600
+    s = (4.0 * 0.97 ** np.arange(n)).astype(np.float32)
+    z = (-0.004 * np.arange(n)).astype(np.float32)
+    p = np.zeros((n, 3, 3), np.float32)
+    p[:, 1, 0] = s; p[:, 2, 1] = s
+    p[:, :, 2] = z[:, None]
+    p[:, :, :2] -= 1.0
+    fs = FlatScene()
+    fs.meshes = [MeshData(positions=p.reshape(-1, 3), indices=np.arange(3 * n, dtype=np.uint32).reshape(n, 3)), _quad(-1.5, 6.0, uv=False)]
+    _mesh_item(fs, 0, Material(base_color=(0.9, 0.6, 0.2), reflectivity=0.2), 2, "fan")
+    _mesh_item(fs, 1, Material(base_color=(0.5, 0.5, 0.6)), 4, "floor")
+    fs.lights = [Light(pos=(2.0, 3.0, 5.0), intensity=60.0)]
+    _cam(fs, eye=(0.5, 0.8, 5.0), direction=(-0.1, -0.15, -1.0))
+    out, _ = _check(hip, oracle, fs, w=128, h=128)
+    assert (out["object_id"] == 2).sum() > 1000
