@@ -1012,3 +1012,11 @@ extern "C" int rr_math_probe(int op, const float* a, const float* b, const float
     }
     return RR_OK;
 }
+
+#ifdef RR_EXP_UTIL
+extern "C" int rr_exp_util(unsigned long long* out32, int reset) {
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_util), sizeof(g_util)) != hipSuccess) return RR_ERR_DEVICE;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_util), z, sizeof(z)) != hipSuccess) return RR_ERR_DEVICE; }
+    return RR_OK;
+}
+#endif

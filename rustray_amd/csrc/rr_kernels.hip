@@ -166,9 +166,39 @@ RR_DEV bool ray_ball(float radius, const LRay& ray, bool solid, float* toi_out, 
     }
 #define RR_SENTINEL ((int)0x80000000) // top-level root of an empty scene
 
+// Developer instrumentation (-DRR_EXP_UTIL): active lanes per executed step, by kind.  Never in the shipped build.
+#ifdef RR_EXP_UTIL
+__device__ unsigned long long g_util[32];
+#define RR_UTIL(slot) { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63u) == __ffsll((long long)m_) - 1) { \
+        atomicAdd(&g_util[2 * (slot)], (unsigned long long)__popcll(m_)); atomicAdd(&g_util[2 * (slot) + 1], 1ull); } }
+#else
+#define RR_UTIL(slot)
+#endif
+
 #ifndef RR_BVH4
 #define RR_BVH4 1
 #endif
+#ifndef RR_TLAS_WW
+#define RR_TLAS_WW 1
+#endif
+// One top-level inner-node step (explicit depth test; an exhausted stack leaves cur = RR_SENTINEL)
+#define RR_TLAS_STEP(bound_expr)                                                                              \
+    {                                                                                                          \
+        RR_UTIL(0) const DNode nd = nodes[cur];                                                                \
+        const float bound = (bound_expr);                                                                      \
+        float e0, e1;                                                                                          \
+        const bool h0 = slab2(nd.n0.x, nd.n0.y, nd.n0.z, nd.n0.w, nd.n2.x, nd.n2.y, sr, bound, &e0);           \
+        const bool h1 = slab2(nd.n1.x, nd.n1.y, nd.n1.z, nd.n1.w, nd.n2.z, nd.n2.w, sr, bound, &e1);           \
+        const int c0 = __float_as_int(nd.n3.x), c1 = __float_as_int(nd.n3.y);                                  \
+        if (h0 && h1) {                                                                                        \
+            const bool swap = e1 < e0;                                                                         \
+            STK(sp) = swap ? c0 : c1; sp++;                                                                    \
+            cur = swap ? c1 : c0;                                                                              \
+        } else if (h0) cur = c0;                                                                               \
+        else if (h1) cur = c1;                                                                                 \
+        else if (sp == 0) cur = RR_SENTINEL;                                                                   \
+        else { sp--; cur = STK(sp); }                                                                          \
+    }
 
 // The traversal's own box test is NOT part of the parity contract (only the exact primitive tests decide
 // hits), so its reciprocal is the hardware approximation.  The subtraction stays in front of the multiply:
@@ -204,7 +234,7 @@ RR_DEV bool slab2(float lox, float hix, float loy, float hiy, float loz, float h
                                    ka = s_ ? kb : ka; ca = s_ ? cb : ca; kb = tk_; cb = tc_; }
 #define RR_NODE4_STEP(nodes4, sr, bound)                                                                       \
     {                                                                                                          \
-        const DNode4* np_ = (nodes4) + cur;                                                                    \
+        RR_UTIL(2) const DNode4* np_ = (nodes4) + cur;                                                         \
         const float4 lx = np_->q[0], hx = np_->q[1], ly = np_->q[2], hy = np_->q[3], lz = np_->q[4], hz = np_->q[5], cc = np_->q[6]; \
         float k0, k1, k2, k3;                                                                                  \
         const bool h0 = slab2(lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, sr, bound, &k0);                             \
@@ -238,6 +268,52 @@ typedef DNode BlasNode;
 // Returns slot (leaf-order triangle index) and side.
 struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool found; };
 
+// Postponed leaves (RR_POSTPONE): a lane that reaches a leaf parks it and keeps walking; the wave tests parked
+// leaves together once RR_PEND_NUM/RR_PEND_DEN of its unfinished lanes hold one, or nobody can walk on.  The
+// order in which triangles are tested is free: the winner is the minimum over (toi, face) and the walk only ever
+// prunes with a bound no smaller than the current best.  (Measured before: node steps ran with ~27 of 64 lanes,
+// triangle tests with 7-15.)
+#ifndef RR_POSTPONE
+#define RR_POSTPONE 1
+#endif
+#ifndef RR_PEND_NUM
+#define RR_PEND_NUM 2
+#define RR_PEND_DEN 3
+#endif
+
+#define RR_LEAF_CLOSEST(leaf)                                                                                  \
+    {                                                                                                          \
+        const uint32_t code = (uint32_t)~(leaf);                                                               \
+        const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);                               \
+        for (uint32_t i = 0; i < count; i++) {                                                                 \
+            RR_UTIL(3)                                                                                         \
+            const DTri tr = tris[first + i];                                                                   \
+            float t; uint32_t side;                                                                            \
+            if (ray_triangle(mk3(tr.v0.x, tr.v0.y, tr.v0.z), mk3(tr.v1.x, tr.v1.y, tr.v1.z),                   \
+                             mk3(tr.v2.x, tr.v2.y, tr.v2.z), ray, &t, &side)) {                                \
+                const uint32_t face = __float_as_uint(tr.v0.w);                                                \
+                if (!best.found || t < best.t || (t == best.t && face < best.face)) {                          \
+                    best.found = true; best.t = t; best.slot = first + i; best.face = face; best.side = side;  \
+                }                                                                                              \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+#define RR_LEAF_ANY(leaf)                                                                                      \
+    {                                                                                                          \
+        const uint32_t code = (uint32_t)~(leaf);                                                               \
+        const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);                               \
+        for (uint32_t i = 0; i < count; i++) {                                                                 \
+            RR_UTIL(3)                                                                                         \
+            const DTri tr = tris[first + i];                                                                   \
+            float t; uint32_t side;                                                                            \
+            if (ray_triangle(mk3(tr.v0.x, tr.v0.y, tr.v0.z), mk3(tr.v1.x, tr.v1.y, tr.v1.z),                   \
+                             mk3(tr.v2.x, tr.v2.y, tr.v2.z), ray, &t, &side)) {                                \
+                any = true;                                                                                    \
+                if (t <= limit) within = true;                                                                 \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+
 RR_DEV void blas_closest(const DSceneView& sc, const DItem& it, const LRay& ray, float gbound,
                          int* s_stack, int sp_base, TriBest* out) {
     TriBest best; best.found = false; best.t = RR_FLT_MAX; best.slot = 0; best.face = 0xffffffffu; best.side = 0u;
@@ -247,26 +323,33 @@ RR_DEV void blas_closest(const DSceneView& sc, const DItem& it, const LRay& ray,
     int sp = sp_base;
     STK(sp) = RR_SENTINEL; sp++;
     int cur = RR_BLAS_ROOT(it);
+    RR_UTIL(4)
+#if RR_POSTPONE
+    int pend = 0; // parked leaf (leaf codes are negative), 0 = none
+    for (;;) {
+        if (cur >= 0) {
+            RR_BLAS_STEP(nodes, sr, fminf(gbound, best.t))
+        } else if (pend == 0 && cur != RR_SENTINEL) {
+            pend = cur; sp--; cur = STK(sp);
+        }
+        const unsigned long long can_walk = __ballot(cur >= 0 || (pend == 0 && cur != RR_SENTINEL));
+        const unsigned long long parked = __ballot(pend != 0);
+        if ((can_walk | parked) == 0ull) break; // every lane of this walk is done
+        const unsigned long long alive = __ballot(cur != RR_SENTINEL || pend != 0);
+        if (can_walk == 0ull || __popcll(parked) * RR_PEND_DEN >= __popcll(alive) * RR_PEND_NUM) {
+            if (pend != 0) { RR_LEAF_CLOSEST(pend) pend = 0; }
+        }
+    }
+#else
     while (cur != RR_SENTINEL) {
         if (cur >= 0) {
             RR_BLAS_STEP(nodes, sr, fminf(gbound, best.t))
         } else {
-            const uint32_t code = (uint32_t)~cur;
-            const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
-            for (uint32_t i = 0; i < count; i++) {
-                const DTri tr = tris[first + i];
-                float t; uint32_t side;
-                if (ray_triangle(mk3(tr.v0.x, tr.v0.y, tr.v0.z), mk3(tr.v1.x, tr.v1.y, tr.v1.z),
-                                 mk3(tr.v2.x, tr.v2.y, tr.v2.z), ray, &t, &side)) {
-                    const uint32_t face = __float_as_uint(tr.v0.w);
-                    if (!best.found || t < best.t || (t == best.t && face < best.face)) {
-                        best.found = true; best.t = t; best.slot = first + i; best.face = face; best.side = side;
-                    }
-                }
-            }
+            RR_LEAF_CLOSEST(cur)
             sp--; cur = STK(sp);
         }
     }
+#endif
     *out = best;
 }
 
@@ -281,26 +364,39 @@ RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, flo
     int sp = sp_base;
     STK(sp) = RR_SENTINEL; sp++;
     int cur = RR_BLAS_ROOT(it);
+    RR_UTIL(4)
+    // until some hit is known every box matters; afterwards only boxes that can still hold a hit within the limit
+#if RR_POSTPONE
+    int pend = 0;
+    for (;;) {
+        if (cur >= 0) {
+            RR_BLAS_STEP(nodes, sr, any ? limit : RR_FLT_MAX)
+        } else if (pend == 0 && cur != RR_SENTINEL) {
+            pend = cur; sp--; cur = STK(sp);
+        }
+        const unsigned long long can_walk = __ballot(cur >= 0 || (pend == 0 && cur != RR_SENTINEL));
+        const unsigned long long parked = __ballot(pend != 0);
+        if ((can_walk | parked) == 0ull) break;
+        const unsigned long long alive = __ballot(cur != RR_SENTINEL || pend != 0);
+        if (can_walk == 0ull || __popcll(parked) * RR_PEND_DEN >= __popcll(alive) * RR_PEND_NUM) {
+            if (pend != 0) {
+                RR_LEAF_ANY(pend)
+                pend = 0;
+                if (within) cur = RR_SENTINEL; // decided: this lane stops walking
+            }
+        }
+    }
+#else
     while (cur != RR_SENTINEL) {
         if (cur >= 0) {
-            // until some hit is known every box matters; afterwards only boxes that can still hold a hit within the limit
             RR_BLAS_STEP(nodes, sr, any ? limit : RR_FLT_MAX)
         } else {
-            const uint32_t code = (uint32_t)~cur;
-            const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
-            for (uint32_t i = 0; i < count; i++) {
-                const DTri tr = tris[first + i];
-                float t; uint32_t side;
-                if (ray_triangle(mk3(tr.v0.x, tr.v0.y, tr.v0.z), mk3(tr.v1.x, tr.v1.y, tr.v1.z),
-                                 mk3(tr.v2.x, tr.v2.y, tr.v2.z), ray, &t, &side)) {
-                    any = true;
-                    if (t <= limit) within = true;
-                }
-            }
+            RR_LEAF_ANY(cur)
             if (within) break;
             sp--; cur = STK(sp);
         }
     }
+#endif
     *found_any = any; *found_within = within;
 }
 
@@ -348,6 +444,7 @@ struct Closest { float t; int item; uint32_t face; float key; bool found; };
 // smaller toi, so among equal toi the smaller (bbox distance, item index) wins.
 RR_DEV void closest_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t depth,
                          int* s_stack, int sp_base, Closest* best) {
+    RR_UTIL(1)
     const DItem& it = sc.items[idx];
     uint32_t flags = it.flags;
     if (!item_passes(flags, false, depth)) return;
@@ -387,6 +484,19 @@ RR_DEV void trace_closest_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, 
     int cur = sc.tlas_root;
     if (cur == RR_SENTINEL) return; // empty scene
     // (at the top level the explicit depth test measured 5-10 % faster than the sentinel form the per-mesh loops use)
+#if RR_TLAS_WW
+    // while-while: every lane walks the top level until it holds a candidate item (or is done), so the per-mesh
+    // walks below run with the lanes of the wave together instead of one straggler at a time
+    for (;;) {
+        while (cur >= 0) { RR_TLAS_STEP(best->t) }
+        if (cur == RR_SENTINEL) break;
+        uint32_t code = (uint32_t)~cur;
+        uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
+        for (uint32_t i = 0; i < count; i++) closest_item(sc, (int)(first + i), o, d, depth, s_stack, sp, best);
+        if (sp == 0) break;
+        sp--; cur = STK(sp);
+    }
+#else
     for (;;) {
         if (cur >= 0) {
             const DNode nd = nodes[cur];
@@ -410,6 +520,7 @@ RR_DEV void trace_closest_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, 
             sp--; cur = STK(sp);
         }
     }
+#endif
 }
 
 // Shadow rays stop at the first ITEM (in bbox-distance order) that is hit at all
@@ -418,6 +529,7 @@ struct ShadowSel { float key; int item; bool found; bool within; float t; uint32
 
 RR_DEV void shadow_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t depth, float limit,
                         int* s_stack, int sp_base, ShadowSel* sel) {
+    RR_UTIL(1)
     const DItem& it = sc.items[idx];
     uint32_t flags = it.flags;
     if (!item_passes(flags, true, depth)) return;
@@ -502,6 +614,18 @@ RR_DEV void trace_shadow_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, f
     int sp = 0;
     int cur = sc.tlas_root;
     if (cur == RR_SENTINEL) return; // empty scene
+#if RR_TLAS_WW
+    for (;;) {
+        // an item whose world box starts beyond the light, or beyond the selected item's key, cannot matter
+        while (cur >= 0) { RR_TLAS_STEP(sel->found ? fminf(limit, sel->key * 1.00001f + 1e-6f) : limit) }
+        if (cur == RR_SENTINEL) break;
+        uint32_t code = (uint32_t)~cur;
+        uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
+        for (uint32_t i = 0; i < count; i++) shadow_item(sc, (int)(first + i), o, d, depth, limit, s_stack, sp, sel);
+        if (sp == 0) break;
+        sp--; cur = STK(sp);
+    }
+#else
     for (;;) {
         if (cur >= 0) {
             const DNode nd = nodes[cur];
@@ -526,6 +650,7 @@ RR_DEV void trace_shadow_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, f
             sp--; cur = STK(sp);
         }
     }
+#endif
     // The occluder found has a hit within the light distance.  Only if its sort key lies beyond the light (its box
     // contains the ray origin, so the key is the box EXIT distance) can an item that starts beyond the light precede it.
     if (sel->found && sel->within && sel->key > limit && trace_shadow_blockers(sc, o, d, depth, limit, *sel, s_stack)) sel->within = false;
