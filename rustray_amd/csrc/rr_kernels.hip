@@ -232,17 +232,43 @@ RR_DEV bool slab2(float lox, float hix, float loy, float hiy, float loz, float h
 // child sorts last and its slot is overwritten), and the nearest taken directly.  Single branch, like the BVH2 step.
 #define RR_CSWAP(ka, ca, kb, cb) { const bool s_ = kb < ka; const float tk_ = s_ ? ka : kb; const int tc_ = s_ ? ca : cb; \
                                    ka = s_ ? kb : ka; ca = s_ ? cb : ca; kb = tk_; cb = tc_; }
-#define RR_NODE4_STEP(nodes4, sr, bound)                                                                       \
+// Per-walk constants of the 4-wide step: the ray in slab form, and for every axis which of the node's two plane
+// rows is the near one for this ray's direction sign (row index 0/1), so that the step loads "near" and "far" rows
+// directly instead of ordering the two plane distances of every child with a min and a max.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct Slab4 { f3 o, inv; uint32_t sx, sy, sz; };
+RR_DEV Slab4 make_slab4(const SlabRay& r) {
+    Slab4 s; s.o = r.o; s.inv = r.inv;
+    s.sx = __float_as_uint(r.inv.x) >> 31; s.sy = __float_as_uint(r.inv.y) >> 31; s.sz = __float_as_uint(r.inv.z) >> 31;
+    return s;
+}
+// (row - o) * inv for the four children of one plane row, as two packed pairs
+#define RR_ROW(row, oc, ic, lo_, hi_) const v2f lo_ = (v2f{row.x, row.y} - v2f{oc, oc}) * v2f{ic, ic}; \
+                                      const v2f hi_ = (v2f{row.z, row.w} - v2f{oc, oc}) * v2f{ic, ic};
+// conservative hit test of one child from its three near and three far plane distances (same slack as slab2)
+#define RR_CHILD(k_, h_, nx, ny, nz, fx, fy, fz)                                                               \
+    float k_; bool h_;                                                                                         \
     {                                                                                                          \
-        RR_UTIL(2) const DNode4* np_ = (nodes4) + cur;                                                         \
-        const float4 lx = np_->q[0], hx = np_->q[1], ly = np_->q[2], hy = np_->q[3], lz = np_->q[4], hz = np_->q[5], cc = np_->q[6]; \
-        float k0, k1, k2, k3;                                                                                  \
-        const bool h0 = slab2(lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, sr, bound, &k0);                             \
-        const bool h1 = slab2(lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, sr, bound, &k1);                             \
-        const bool h2 = slab2(lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, sr, bound, &k2);                             \
-        const bool h3 = slab2(lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, sr, bound, &k3);                             \
+        const float tn_ = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));                                               \
+        const float tf_ = fminf(fminf(fx, fy), fminf(fz, RR_FLT_MAX));                                         \
+        const float tc_ = tn_ * 0.999996f;                                                                     \
+        h_ = tc_ <= tf_ * 1.000004f && tc_ <= bound_;                                                          \
+        k_ = h_ ? tn_ : inf_;                                                                                  \
+    }
+#define RR_NODE4_STEP(nodes4, s4, bound)                                                                       \
+    {                                                                                                          \
+        RR_UTIL(2) const float4* np_ = (const float4*)((nodes4) + cur);                                        \
+        const float4 rnx = np_[(s4).sx], rfx = np_[1u - (s4).sx], rny = np_[2u + (s4).sy], rfy = np_[3u - (s4).sy];             \
+        const float4 rnz = np_[4u + (s4).sz], rfz = np_[5u - (s4).sz], cc = np_[6];                           \
+        const float bound_ = (bound);                                                                          \
         const float inf_ = __builtin_inff();                                                                   \
-        k0 = h0 ? k0 : inf_; k1 = h1 ? k1 : inf_; k2 = h2 ? k2 : inf_; k3 = h3 ? k3 : inf_;                    \
+        RR_ROW(rnx, (s4).o.x, (s4).inv.x, nx01, nx23) RR_ROW(rfx, (s4).o.x, (s4).inv.x, fx01, fx23)            \
+        RR_ROW(rny, (s4).o.y, (s4).inv.y, ny01, ny23) RR_ROW(rfy, (s4).o.y, (s4).inv.y, fy01, fy23)            \
+        RR_ROW(rnz, (s4).o.z, (s4).inv.z, nz01, nz23) RR_ROW(rfz, (s4).o.z, (s4).inv.z, fz01, fz23)            \
+        RR_CHILD(k0, h0, nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x)                                       \
+        RR_CHILD(k1, h1, nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y)                                       \
+        RR_CHILD(k2, h2, nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x)                                       \
+        RR_CHILD(k3, h3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y)                                       \
         int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w); \
         RR_CSWAP(k0, c0, k1, c1) RR_CSWAP(k2, c2, k3, c3) RR_CSWAP(k0, c0, k2, c2) RR_CSWAP(k1, c1, k3, c3) RR_CSWAP(k1, c1, k2, c2) \
         STK(sp) = c3; sp += (k3 < inf_) ? 1 : 0;                                                               \
@@ -254,12 +280,16 @@ RR_DEV bool slab2(float lox, float hix, float loy, float hiy, float loz, float h
 #define RR_BLAS_NODES(sc, it) ((sc).nodes4 + (it).node_base4)
 #define RR_BLAS_ROOT(it) ((it).root4)
 #define RR_BLAS_STEP(nodes, sr, bound) RR_NODE4_STEP(nodes, sr, bound)
+#define RR_BLAS_SLAB(r) make_slab4(make_slab((r).o, (r).d))
 typedef DNode4 BlasNode;
+typedef Slab4 BlasSlab;
 #else
 #define RR_BLAS_NODES(sc, it) ((sc).nodes + (it).node_base)
 #define RR_BLAS_ROOT(it) ((it).root)
 #define RR_BLAS_STEP(nodes, sr, bound) RR_NODE_STEP(nodes, sr, bound)
+#define RR_BLAS_SLAB(r) make_slab((r).o, (r).d)
 typedef DNode BlasNode;
+typedef SlabRay BlasSlab;
 #endif
 
 // Nearest triangle of one mesh (TriMesh::cast_local_ray_and_get_normal,
@@ -317,7 +347,7 @@ struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool foun
 RR_DEV void blas_closest(const DSceneView& sc, const DItem& it, const LRay& ray, float gbound,
                          int* s_stack, int sp_base, TriBest* out) {
     TriBest best; best.found = false; best.t = RR_FLT_MAX; best.slot = 0; best.face = 0xffffffffu; best.side = 0u;
-    const SlabRay sr = make_slab(ray.o, ray.d);
+    const BlasSlab sr = RR_BLAS_SLAB(ray);
     const BlasNode* nodes = RR_BLAS_NODES(sc, it);
     const DTri* tris = sc.tris + it.tri_base;
     int sp = sp_base;
@@ -358,7 +388,7 @@ RR_DEV void blas_closest(const DSceneView& sc, const DItem& it, const LRay& ray,
 RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, float limit,
                      int* s_stack, int sp_base, bool* found_any, bool* found_within) {
     bool any = false, within = false;
-    const SlabRay sr = make_slab(ray.o, ray.d);
+    const BlasSlab sr = RR_BLAS_SLAB(ray);
     const BlasNode* nodes = RR_BLAS_NODES(sc, it);
     const DTri* tris = sc.tris + it.tri_base;
     int sp = sp_base;
