@@ -266,6 +266,19 @@ int rr_sample_table(uint16_t samples, uint16_t* xy_out, uint32_t* cell_size_out)
 int rr_render(rr_scene* scene, const rr_camera* camera, const rr_config* config,
               const uint16_t* sample_xy, const rr_frame* out, const volatile int* cancel);
 
+/* Progressive form of rr_render.  Stands in for the progressive fill the reference shows while a frame renders:
+ * Run::apply_pixels drains the PixelData channel every GUI tick (src/run.rs:506-545) and RendererManager::stop
+ * (src/renderer.rs:174-198) ends the frame early.  The frame is rendered in at least `min_passes` device batches of
+ * whole sample slices (every pixel, a subset of the samples); after each batch but the last, the host buffers of
+ * `out` hold the frame resolved over the samples finished so far (colour, normal and depth are means; object_id is
+ * only final after the last batch) and `on_pass(user, samples_done, samples_total)` is called on the calling
+ * thread.  A non-zero return stops the frame: the call returns RR_ERR_CANCELLED and `out` keeps the last preview.
+ * The finished frame is bit-identical to rr_render's. */
+typedef int (*rr_pass_fn)(void* user, uint64_t primary_samples_done, uint64_t primary_samples_total);
+int rr_render_progressive(rr_scene* scene, const rr_camera* camera, const rr_config* config,
+                          const uint16_t* sample_xy, const rr_frame* out, uint32_t min_passes,
+                          rr_pass_fn on_pass, void* user, const volatile int* cancel);
+
 /* Number of pixels `region` owns in a width x height frame. */
 uint64_t rr_region_pixel_count(uint32_t width, uint32_t height, const rr_region* region);
 

@@ -103,6 +103,17 @@ class Animation:
         rotation = lerp(a.rotation, b.rotation, (0.0, 0.0, 0.0))
         return get_transformation(np.eye(4, dtype=F32), translation, scale, rotation)
 
+    def frame_exists(self, frame: int) -> bool:
+        """Scene::frame_exists (reference src/scene.rs:1690-1693)."""
+        return self.has_animation() and frame < self.get_frames_amount_to_render()
+
+    def frames_to_render(self, start: int = 0):
+        """Frames the reference's loop visits (src/run.rs:421-465): `start`, then every next frame that exists."""
+        frames = [start]
+        while self.frame_exists(frames[-1] + 1):
+            frames.append(frames[-1] + 1)
+        return frames
+
     # -- Scene::apply_frame (reference src/scene.rs:1695-1713) on a flat scene ----------------------
     def frame_transforms(self, flat_scene, frame: int):
         """(trans, trans_inv) arrays (n_items, 4, 4) for `frame`, or None when the reference would not touch the scene."""

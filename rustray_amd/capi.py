@@ -29,6 +29,9 @@ class RustrayHipError(RuntimeError):
         self.code = code
 
 
+PASS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64)
+
+
 def build(force: bool = False) -> str:
     """Compile librustray_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     csrc = os.path.join(_HERE, "csrc")
@@ -54,6 +57,8 @@ def lib():
         L.rr_scene_update_transforms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rr_sample_table.argtypes = [C.c_uint16, C.c_void_p, C.POINTER(C.c_uint32)]
         L.rr_render.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p, C.POINTER(rr_frame), C.c_void_p]
+        L.rr_render_progressive.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p, C.POINTER(rr_frame),
+                                            C.c_uint32, PASS_FN, C.c_void_p, C.c_void_p]
         L.rr_render_region_device.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p,
                                               C.POINTER(rr_region), C.POINTER(rr_frame), C.c_void_p, C.c_void_p]
         L.rr_deinterleave_device.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -138,6 +143,34 @@ class DeviceScene:
             fr = rr_frame(rgba.ctypes.data, out["normal"].ctypes.data, out["depth"].ctypes.data, out["object_id"].ctypes.data)
         keep, p = _sxy(sample_xy)
         _check(lib().rr_render(self._h, C.byref(cam), C.byref(cfg), p, C.byref(fr), None))
+        return out
+
+    def render_progressive(self, cam: rr_camera, cfg: rr_config, on_pass, min_passes: int = 8, sample_xy=None, aux: bool = True):
+        """rr_render_progressive: `on_pass(out, samples_done, samples_total)` sees the frame resolved over the samples
+        finished so far after every device batch; a truthy return stops the frame (RustrayHipError, code -6)."""
+        w, h = cam.width, cam.height
+        rgba = np.zeros((h, w, 4), np.uint8)
+        out = dict(rgba=rgba)
+        fr = rr_frame(rgba.ctypes.data, None, None, None)
+        if aux:
+            out["normal"] = np.zeros((h, w, 3), np.float32)
+            out["depth"] = np.zeros((h, w), np.float32)
+            out["object_id"] = np.zeros((h, w), np.uint32)
+            fr = rr_frame(rgba.ctypes.data, out["normal"].ctypes.data, out["depth"].ctypes.data, out["object_id"].ctypes.data)
+        keep, p = _sxy(sample_xy)
+        errors = []
+
+        def _cb(user, done, total):
+            try:
+                return 1 if on_pass(out, int(done), int(total)) else 0
+            except BaseException as e:  # an exception must not unwind through the C frames
+                errors.append(e)
+                return 1
+        cb = PASS_FN(_cb)
+        rc = lib().rr_render_progressive(self._h, C.byref(cam), C.byref(cfg), p, C.byref(fr), int(min_passes), cb, None, None)
+        if errors:
+            raise errors[0]
+        _check(rc)
         return out
 
     # -- one rank's region into device (torch) tensors ----------------------------

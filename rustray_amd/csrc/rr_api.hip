@@ -637,8 +637,16 @@ static void resolve_timers(rr_scene* s) {
     s->timed.clear();
 }
 
+// Progressive preview (rr_render_progressive): after every device batch that ends on a whole slice of samples the
+// accumulators are resolved over the samples finished so far and handed to the caller.
+struct PassHook {
+    rr_pass_fn fn; void* user; uint32_t min_passes;
+    void* host[4]; size_t bytes[4];
+};
+
 static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy,
-                                const rr_region* rg, const rr_frame* out, bool frame_layout, hipStream_t st, const volatile int* cancel) {
+                                const rr_region* rg, const rr_frame* out, bool frame_layout, hipStream_t st, const volatile int* cancel,
+                                const PassHook* hook = nullptr) {
     HIP_TRY(hipSetDevice(s->device));
     if (st != s->last_stream) { HIP_TRY(hipStreamSynchronize(s->last_stream)); s->last_stream = st; }
     const uint32_t W = cam->width, H = cam->height;
@@ -725,6 +733,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     B = std::max<uint64_t>(B, 4096);
     B = std::min<uint64_t>(B, total_primary);
     B = std::min<uint64_t>(B, 0x7fffffffull / std::max<uint64_t>(f_odd, 1));
+    if (hook && hook->min_passes > 1) B = std::min<uint64_t>(B, std::max<uint64_t>(npix, (total_primary + hook->min_passes - 1) / hook->min_passes));
     // equal batches (a frame that needs 1.2 batches would otherwise end with a small, poorly filled one)
     { const uint64_t nb = (total_primary + B - 1) / B; B = (total_primary + nb - 1) / nb; }
     if (B > npix) B = ((B + npix - 1) / npix) * npix; // whole sample slices when possible
@@ -806,6 +815,18 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         HIP_TRY(hipGetLastError());
         // batches are stream-ordered; only a caller that can cancel needs the host to keep pace with the device
         if (cancel && first + B < total_primary) HIP_TRY(hipStreamSynchronize(st));
+        const uint64_t done = first + n_batch;
+        if (hook && hook->fn && done < total_primary && done % npix == 0) {
+            DFrame pf = fr;
+            pf.samples = (uint32_t)(done / npix); // the mean over the sample slices finished so far
+            hipLaunchKernelGGL(k_resolve, dim3((npix + RR_BLOCK - 1) / RR_BLOCK), dim3(RR_BLOCK), 0, st, pf, s->region_xy.as<uint32_t>(), s->trace_order.as<uint32_t>(), acc,
+                               out->rgba8, out->normal, out->depth, out->object_id, frame_layout ? 1u : 0u);
+            void* const dev[4] = {out->rgba8, out->normal, out->depth, out->object_id};
+            for (int k = 0; k < 4; k++)
+                if (hook->host[k] && dev[k]) HIP_TRY(hipMemcpyAsync(hook->host[k], dev[k], hook->bytes[k], hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (hook->fn(hook->user, done, total_primary) != 0) return fail(RR_ERR_CANCELLED, "stopped by the pass callback");
+        }
     }
     hipLaunchKernelGGL(k_resolve, dim3((npix + RR_BLOCK - 1) / RR_BLOCK), dim3(RR_BLOCK), 0, st, fr, s->region_xy.as<uint32_t>(), s->trace_order.as<uint32_t>(), acc,
                        out->rgba8, out->normal, out->depth, out->object_id, frame_layout ? 1u : 0u);
@@ -825,8 +846,8 @@ extern "C" int rr_render_region_device(rr_scene* s, const rr_camera* cam, const 
     return render_region_locked(s, cam, cfg, sample_xy, rg, out, false, (hipStream_t)hip_stream, cancel);
 }
 
-extern "C" int rr_render(rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy, const rr_frame* out,
-                         const volatile int* cancel) {
+static int render_to_host(rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy, const rr_frame* out,
+                          const volatile int* cancel, rr_pass_fn fn, void* user, uint32_t min_passes) {
     int rc = check_frame_args(s, cam, cfg);
     if (rc != RR_OK) return rc;
     if (!out || !out->rgba8) return fail(RR_ERR_INVALID_ARGUMENT, "out->rgba8 is required");
@@ -840,12 +861,24 @@ extern "C" int rr_render(rr_scene* s, const rr_camera* cam, const rr_config* cfg
     for (int k = 0; k < 4; k++)
         if (host[k]) { HIP_TRY(s->tmp_out[k].reserve(bytes[k])); *devp[k] = s->tmp_out[k].p; }
     rr_region whole{8, 8, 1, 0}; // 8x8 tiles: one wave = one tile of primary rays
-    rc = render_region_locked(s, cam, cfg, sample_xy, &whole, &dev, true, nullptr, cancel);
+    PassHook hook{fn, user, min_passes, {host[0], host[1], host[2], host[3]}, {bytes[0], bytes[1], bytes[2], bytes[3]}};
+    rc = render_region_locked(s, cam, cfg, sample_xy, &whole, &dev, true, nullptr, cancel, fn ? &hook : nullptr);
     if (rc != RR_OK) return rc;
     HIP_TRY(hipStreamSynchronize(nullptr));
     for (int k = 0; k < 4; k++)
         if (host[k]) HIP_TRY(hipMemcpy(host[k], s->tmp_out[k].p, bytes[k], hipMemcpyDeviceToHost));
     return RR_OK;
+}
+
+extern "C" int rr_render(rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy, const rr_frame* out,
+                         const volatile int* cancel) {
+    return render_to_host(s, cam, cfg, sample_xy, out, cancel, nullptr, nullptr, 0);
+}
+
+extern "C" int rr_render_progressive(rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy, const rr_frame* out,
+                                     uint32_t min_passes, rr_pass_fn on_pass, void* user, const volatile int* cancel) {
+    if (!on_pass) return fail(RR_ERR_INVALID_ARGUMENT, "on_pass is required (use rr_render for a one-shot frame)");
+    return render_to_host(s, cam, cfg, sample_xy, out, cancel, on_pass, user, min_passes);
 }
 
 extern "C" int rr_scene_last_stats(const rr_scene* cs, rr_frame_stats* out) {

@@ -75,13 +75,33 @@ class RendererManager:
     def update_resolution(self, width: int, height: int):
         self.width, self.height = width, height
 
-    def start(self):
+    def start(self, on_pass=None, min_passes: int = 8):
+        """One frame.  With `on_pass(manager)` the frame is rendered progressively: after every device batch the
+        image buffers hold the frame over the samples finished so far (what Run::apply_pixels shows while the
+        reference renders, src/run.rs:506-545) and the callback may call `stop()` to end the frame early
+        (RendererManager::stop, src/renderer.rs:174-198)."""
         self._start = time.time()
         self._done_ms = 0
         self._pixels_rendered = 0
         self._running = True
         self.raytracing.camera.init(self.width, self.height)
-        out = self.raytracing.render_frame()
+        if on_pass is not None:
+            def _pass(out, done, total):
+                self.image, self.normals, self.depth, self.objects = out["rgba"], out["normal"], out["depth"], out["object_id"]
+                # the reference counts finished pixels; a pass finishes a share of every pixel's samples
+                self._pixels_rendered = (self.width * self.height * done) // total
+                on_pass(self)
+                return not self._running
+            try:
+                out = self.raytracing.device_scene.render_progressive(self.raytracing.camera.c_struct(), self.raytracing.config,
+                                                                      _pass, min_passes=min_passes)
+            except capi.RustrayHipError as e:
+                if e.code != -6:
+                    raise
+                self._done_ms = int((time.time() - self._start) * 1000.0)
+                return  # stopped: the buffers keep the last preview
+        else:
+            out = self.raytracing.render_frame()
         # what Run::apply_pixels stores per PixelData (src/run.rs:519-541)
         self.image, self.normals, self.depth, self.objects = out["rgba"], out["normal"], out["depth"], out["object_id"]
         self._pixels_rendered = self.width * self.height
@@ -106,6 +126,70 @@ class RendererManager:
 
     def check_and_get_elapsed_time(self) -> int:
         return self._done_ms if self._done_ms > 0 else int((time.time() - self._start) * 1000.0)
+
+
+# ---------------------------------------------------------------------------
+# animation: the frame loop, one frame per GPU at a time
+# ---------------------------------------------------------------------------
+class AnimationRun:
+    """The reference's animation loop (Run::render_next_frame_if_possible, src/run.rs:421-465: apply_frame, restart,
+    wait for completion, next frame) over ONE resident device scene: only the item transforms change per frame
+    (Scene::apply_frame, src/scene.rs:1695-1713 -> rr_scene_update_transforms), geometry, per-mesh trees and textures
+    stay in HBM.  With world_size > 1 the frames are dealt round-robin to the ranks (one process per GPU, scene
+    replicated): frames are independent, so the data path needs no collective; `gather()` brings the finished
+    RGBA8 frames to rank 0 if one process is to write them out."""
+
+    def __init__(self, raytracing: Raytracing, animation, rank: int = 0, world_size: int = 1, start_frame: int = 0):
+        self.raytracing, self.animation = raytracing, animation
+        self.rank, self.world_size = rank, world_size
+        self.frames = animation.frames_to_render(start_frame)
+
+    def my_frames(self, rank: Optional[int] = None):
+        r = self.rank if rank is None else rank
+        return self.frames[r::self.world_size]
+
+    def render(self, on_frame=None, render_fn=None) -> dict:
+        """{frame: out} for this rank's frames.  render_fn(frame) replaces the device call (host-logic tests)."""
+        done = {}
+        for f in self.my_frames():
+            if render_fn is not None:
+                out = render_fn(f)
+            else:
+                tr = self.animation.frame_transforms(self.raytracing.flat_scene, f)
+                if tr is not None:
+                    self.raytracing.device_scene.update_transforms(*tr)
+                out = self.raytracing.render_frame()
+            done[f] = out
+            if on_frame is not None:
+                on_frame(f, out)
+        return done
+
+    def gather(self, done: dict, via_cpu: bool = False):
+        """Rank 0: list of (frame, rgba) in frame order; other ranks: None.  One gather of the stacked RGBA8 frames."""
+        import torch
+        import torch.distributed as dist
+        mine = self.my_frames()
+        if self.world_size == 1:
+            return [(f, done[f]["rgba"]) for f in mine]
+        h, w = (done[mine[0]]["rgba"].shape[:2]) if mine else (0, 0)
+        shape = torch.tensor([h, w], dtype=torch.int64)
+        dist.all_reduce(shape, op=dist.ReduceOp.MAX)  # a rank without frames still needs the shape
+        h, w = int(shape[0]), int(shape[1])
+        n_max = max(len(self.my_frames(r)) for r in range(self.world_size))
+        pad = torch.zeros((n_max, h, w, 4), dtype=torch.uint8)
+        for i, f in enumerate(mine):
+            pad[i] = torch.from_numpy(np.ascontiguousarray(done[f]["rgba"]))
+        if not via_cpu and torch.cuda.is_available() and dist.get_backend() == "nccl":
+            pad = pad.cuda()
+        gl = [torch.empty_like(pad) for _ in range(self.world_size)] if self.rank == 0 else None
+        dist.gather(pad, gl, dst=0)
+        if self.rank != 0:
+            return None
+        out = []
+        for r in range(self.world_size):
+            for i, f in enumerate(self.my_frames(r)):
+                out.append((f, gl[r][i].cpu().numpy()))
+        return sorted(out, key=lambda t: t[0])
 
 
 # ---------------------------------------------------------------------------

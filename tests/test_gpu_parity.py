@@ -307,3 +307,64 @@ def test_shadow_blocker_beyond_the_light(hip, oracle):
     with hip.DeviceScene(fs, 0) as ds:
         out = ds.render(cam, cfg)
     assert_parity(out, ref, "blocker beyond the light")
+
+
+def test_progressive_passes_refine_towards_the_one_shot_frame(hip):
+    """rr_render_progressive (the reference shows the frame filling in while it renders, src/run.rs:506-545): every pass
+    reports more samples, previews are whole frames, the finished frame is bit-identical to rr_render's, and a callback
+    can stop the frame (RendererManager::stop, src/renderer.rs:174-198)."""
+    fs = load_scene("spheres_room")
+    cam = camera_for(fs, 96, 64).c_struct()
+    cfg = make_config(samples=16, monte_carlo=True, seed=4)
+    with hip.DeviceScene(fs, 0) as ds:
+        ref = ds.render(cam, cfg)
+        seen, errs = [], []
+
+        def on_pass(out, done, total):
+            seen.append((done, total))
+            # a preview is the mean over the finished sample slices: already close to the final frame
+            errs.append(float(np.abs(out["rgba"][..., :3].astype(np.int32) - ref["rgba"][..., :3].astype(np.int32)).mean()))
+            assert out["rgba"][..., 3].min() == 255
+            return False
+        out = ds.render_progressive(cam, cfg, on_pass, min_passes=4)
+        for k in ("rgba", "normal", "depth", "object_id"):
+            assert np.array_equal(out[k], ref[k]), k
+        assert len(seen) >= 3 and all(t == 96 * 64 * 16 for _, t in seen)
+        assert [d for d, _ in seen] == sorted(set(d for d, _ in seen)) and all(d % (96 * 64) == 0 for d, _ in seen)
+        assert errs[-1] <= errs[0] and errs[-1] < 12.0
+        # stopping after the first pass keeps that preview and reports the cancellation
+        with pytest.raises(hip.RustrayHipError) as e:
+            ds.render_progressive(cam, cfg, lambda out, done, total: True, min_passes=4)
+        assert e.value.code == -6
+        # the scene is still usable
+        assert np.array_equal(ds.render(cam, cfg)["rgba"], ref["rgba"])
+
+
+def test_animation_run_equals_frame_by_frame_updates(hip):
+    """AnimationRun (frame loop of src/run.rs:421-465 on one resident scene) gives the frames that separate
+    update_transforms + render calls give; RendererManager.start(on_pass=...) can stop a frame early."""
+    from rustray_amd.animation import Animation, Frame, Keyframe
+    from rustray_amd.renderer import AnimationRun, Raytracing, RendererManager
+    fs = load_scene("monkey_room")
+    name = fs.items[0].name
+    an = Animation(True, 3, [Keyframe(0, [Frame(name, (0.0, 0.0, -10.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))]),
+                             Keyframe(1000, [Frame(name, (1.0, 0.5, -9.0), (0.0, 2.0, 0.3), (1.4, 1.4, 1.4))])])
+    rt = Raytracing(fs, camera_for(fs, 64, 48))
+    rt.apply_config(samples=2, monte_carlo=True, seed=2)
+    try:
+        run = AnimationRun(rt, an)
+        assert run.frames == [0, 1, 2]
+        frames = run.render()
+        for f in run.frames:
+            rt.device_scene.update_transforms(*an.frame_transforms(fs, f))
+            assert np.array_equal(frames[f]["rgba"], rt.render_frame()["rgba"]), f
+        assert not np.array_equal(frames[0]["rgba"], frames[2]["rgba"])
+        mgr = RendererManager(64, 48, rt)
+        rt.apply_config(samples=16)
+        calls = []
+        mgr.start(on_pass=lambda m: (calls.append(m.get_rendered_pixels()), m.stop()), min_passes=4)
+        assert len(calls) == 1 and 0 < calls[0] < 64 * 48 and not mgr.is_done() and mgr.image is not None
+        mgr.start()
+        assert mgr.is_done()
+    finally:
+        rt.close()

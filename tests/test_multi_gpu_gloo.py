@@ -53,3 +53,36 @@ def test_two_rank_gather_reassembles_the_frame(w, h, tw, th):
     tiles_x = (w + tw - 1) // tw
     owner = ((ys // th) * tiles_x + xs // tw) % world + 1
     assert (ret["object_id"][..., 0] == owner).all()
+
+
+def _anim_worker(rank, world, port, ret):
+    from rustray_amd.animation import Animation, Frame, Keyframe
+    from rustray_amd.renderer import AnimationRun
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    an = Animation(True, 7, [Keyframe(0, [Frame("a", (0.0, 0.0, 0.0), None, None)]), Keyframe(1000, [Frame("a", (1.0, 0.0, 0.0), None, None)])])
+    run = AnimationRun(None, an, rank, world)
+    seen = []
+    done = run.render(on_frame=lambda f, out: seen.append(f),
+                      render_fn=lambda f: {"rgba": np.full((6, 5, 4), f * 10 + rank, np.uint8)})
+    assert seen == run.my_frames() == run.frames[rank::world]
+    got = run.gather(done, via_cpu=True)
+    if rank == 0:
+        ret["frames"] = [f for f, _ in got]
+        ret["values"] = [int(img[0, 0, 0]) for _, img in got]
+        ret["n"] = len(run.frames)
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_animation_frames_are_dealt_to_the_ranks_and_gathered_in_order(world):
+    """Frame-per-GPU animation: 7 frames over 2 / 3 ranks, no data-path collective, one gather."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_anim_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret["n"] == 7 and ret["frames"] == list(range(7))
+    assert ret["values"] == [f * 10 + f % world for f in range(7)]
