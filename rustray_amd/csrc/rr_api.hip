@@ -377,11 +377,12 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         d.alpha = m.alpha; d.shininess = m.shininess; d.reflectivity = m.reflectivity; d.refraction_index = m.refraction_index;
         d.normal_map_strength = m.normal_map_strength; d.shadow_softness = m.shadow_softness; d.roughness = m.roughness;
         bool any = false;
+        uint32_t slots = 0u;
         for (int k = 0; k < RR_TEX_COUNT; k++) {
             d.tex[k] = m.texture[k];
-            if (m.texture[k] >= 0 && fs->textures[m.texture[k]].width > 0) any = true; // has_texture: width > 0
+            if (m.texture[k] >= 0 && fs->textures[m.texture[k]].width > 0) { any = true; slots |= RR_MF_TEX_SLOT0 << k; } // has_texture: width > 0
         }
-        d.flags = (m.texture_filtering_nearest ? RR_MF_NEAREST : 0u) | (m.receive_shadow ? RR_MF_RECEIVE_SHADOW : 0u) |
+        d.flags = slots | (m.texture_filtering_nearest ? RR_MF_NEAREST : 0u) | (m.receive_shadow ? RR_MF_RECEIVE_SHADOW : 0u) |
                   (m.monte_carlo ? RR_MF_MONTE_CARLO : 0u) | (any ? RR_MF_ANY_TEX : 0u);
     }
     HIP_TRY(s->materials.reserve(std::max<size_t>(dmat.size(), 1) * sizeof(DMaterial)));

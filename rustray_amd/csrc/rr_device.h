@@ -79,10 +79,10 @@ struct DMaterial {
     float specular[3]; float reflectivity;
     float refraction_index, normal_map_strength, shadow_softness, roughness;
     int32_t tex[8];
-    uint32_t flags; // bit0 nearest filtering, bit1 receive_shadow, bit2 monte_carlo, bit3 any texture
+    uint32_t flags; // bit0 nearest filtering, bit1 receive_shadow, bit2 monte_carlo, bit3 any texture, bits 8..15 slot k holds a texture
     uint32_t _pad[3];
 };
-enum : uint32_t { RR_MF_NEAREST = 1u, RR_MF_RECEIVE_SHADOW = 2u, RR_MF_MONTE_CARLO = 4u, RR_MF_ANY_TEX = 8u };
+enum : uint32_t { RR_MF_NEAREST = 1u, RR_MF_RECEIVE_SHADOW = 2u, RR_MF_MONTE_CARLO = 4u, RR_MF_ANY_TEX = 8u, RR_MF_TEX_SLOT0 = 256u };
 
 struct DTexture { uint64_t offset; uint32_t width, height; }; // offset in texels into the RGBA8 pool
 

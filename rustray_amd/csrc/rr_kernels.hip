@@ -716,6 +716,33 @@ RR_DEV float4 tex_bilinear(const DSceneView& sc, const DTexture& t, float u, flo
     float4 b = make_float4(lerp1(p2.x, p3.x, fx), lerp1(p2.y, p3.y, fx), lerp1(p2.z, p3.z, fx), lerp1(p2.w, p3.w, fx));
     return make_float4(lerp1(a.x, b.x, fy), lerp1(a.y, b.y, fy), lerp1(a.z, b.z, fy), lerp1(a.w, b.w, fy));
 }
+// The material of a hit, copied into registers once (four 16-B loads + the flag word): the shading code stores to
+// queues and accumulators between its uses, so fields read through the pointer would be re-fetched one dword at a
+// time, each fetch a dependent round trip.  Texture slots are only looked at when the flag word says they are set.
+struct MatR {
+    f3 ambient, base, specular;
+    float alpha, shininess, reflectivity, refraction_index, normal_map_strength, shadow_softness, roughness;
+    uint32_t flags;
+    const DMaterial* p;
+};
+RR_DEV MatR load_material(const DMaterial* p) {
+    const float4* q = (const float4*)p;
+    const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+    MatR m;
+    m.ambient = mk3(a.x, a.y, a.z); m.alpha = a.w;
+    m.base = mk3(b.x, b.y, b.z); m.shininess = b.w;
+    m.specular = mk3(c.x, c.y, c.z); m.reflectivity = c.w;
+    m.refraction_index = d.x; m.normal_map_strength = d.y; m.shadow_softness = d.z; m.roughness = d.w;
+    m.flags = p->flags; m.p = p;
+    return m;
+}
+RR_DEV bool tex_color(const DSceneView& sc, const MatR& m, bool has_uv, f2 uv, int slot, float4* out) {
+    if (!(m.flags & (RR_MF_TEX_SLOT0 << slot)) || !has_uv) return false; // slot bit = index >= 0 and width > 0
+    const DTexture t = sc.textures[m.p->tex[slot]];
+    if (m.flags & RR_MF_NEAREST) *out = texel(sc, t, tex_wrap(uv.x, t.width), tex_wrap(uv.y, t.height));
+    else *out = tex_bilinear(sc, t, uv.x, uv.y);
+    return true;
+}
 // get_tex_color: false = None
 RR_DEV bool tex_color(const DSceneView& sc, const DMaterial& m, bool has_uv, f2 uv, int slot, float4* out) {
     int ti = m.tex[slot];
@@ -964,8 +991,8 @@ RR_DEV uint32_t wave_alloc(uint32_t* counter, bool want, uint32_t lane) {
 }
 
 // get_item_color, reference src/raytracing.rs:677-712
-RR_DEV float4 item_color(const DSceneView& sc, const DMaterial& m, bool has_uv, f2 uv, const float* rgb, int slot) {
-    float4 c = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+RR_DEV float4 item_color(const DSceneView& sc, const MatR& m, bool has_uv, f2 uv, f3 rgb, int slot) {
+    float4 c = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
     float4 t;
     if (tex_color(sc, m, has_uv, uv, slot, &t)) { c.x *= t.x; c.y *= t.y; c.z *= t.z; c.w *= t.w; }
     return c;
@@ -1012,7 +1039,8 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         const bool idc = ((meta >> 24) & 1u) != 0u;
         const float thr = r0.w;
         const DItem& it = sc.items[item_idx];
-        const DMaterial& m = sc.materials[it.material];
+        const uint32_t it_flags = it.flags, it_tri_base = it.tri_base, it_id = it.id; // register copies (see MatR)
+        const MatR m = load_material(&sc.materials[it.material]);
         const f3 ro = mk3(r0.x, r0.y, r0.z), rd = mk3(r1.x, r1.y, r1.z);
         const float hit_dist = __uint_as_float(hit.x);
         const f3 hit_point = ro + (rd * hit_dist);
@@ -1021,17 +1049,17 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
 
         // ---- world normal: Shape::intersect (mesh.rs:76-98, sphere.rs:61-65)
         f3 normal;
-        if (it.flags & RR_IF_SPHERE) {
+        if (it_flags & RR_IF_SPHERE) {
             LRay lr = inverse_ray(it, ro, rd, gw);
             float t2 = 0.0f; bool inside = false;
-            ray_ball(it.radius, lr, (it.flags & RR_IF_SOLID_BASE) != 0u, &t2, &inside);
+            ray_ball(it.radius, lr, (it_flags & RR_IF_SOLID_BASE) != 0u, &t2, &inside);
             f3 nl = normalize3(lr.o + lr.d * t2);
             normal = to_world_normal(it, inside ? -nl : nl);
         } else {
-            const DTri tr = sc.tris[it.tri_base + slot];
+            const DTri tr = sc.tris[it_tri_base + slot];
             const f3 a = mk3(tr.v0.x, tr.v0.y, tr.v0.z), b = mk3(tr.v1.x, tr.v1.y, tr.v1.z), c = mk3(tr.v2.x, tr.v2.y, tr.v2.z);
-            if (it.flags & RR_IF_SMOOTH) {
-                const DTriAttr at = sc.attrs[it.tri_base + slot];
+            if (it_flags & RR_IF_SMOOTH) {
+                const DTriAttr at = sc.attrs[it_tri_base + slot];
                 f3 p = to_local_point(it, hit_point, gw);
                 float a1, a2, a3;
                 area_weights(a, b, c, p, &a1, &a2, &a3);
@@ -1042,7 +1070,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
                 f3 ng = normalize3(cross3(b - a, c - a));
                 normal = to_world_normal(it, neg ? -ng : ng);
             }
-            if (it.flags & RR_IF_FLIP_NORMALS) normal = -normal;
+            if (it_flags & RR_IF_FLIP_NORMALS) normal = -normal;
         }
         // ---- aux outputs of the root node (:742-744, :400-402)
         if (depth == 1u) {
@@ -1057,7 +1085,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         // ---- uv (:749-754)
         bool has_uv = false; f2 uv; uv.x = 0.0f; uv.y = 0.0f;
         if (m.flags & RR_MF_ANY_TEX) {
-            uv = (it.flags & RR_IF_SPHERE) ? sphere_uv(it, hit_point, gw) : mesh_uv(sc, it, slot, hit_point, gw);
+            uv = (it_flags & RR_IF_SPHERE) ? sphere_uv(it, hit_point, gw) : mesh_uv(sc, it, slot, hit_point, gw);
             has_uv = true;
         }
         f3 surface_normal = normal;
@@ -1141,7 +1169,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         }
         // ---- object id (:744, :966-969): the last sample's id, passed through fully transparent hits
         const bool child_idc = idc && spawn_refr && approx_equal(alpha, 0.0f);
-        if (acc.object_id && idc && !child_idc && sample + 1u == fr.samples) acc.object_id[pix] = it.id;
+        if (acc.object_id && idc && !child_idc && sample + 1u == fr.samples) acc.object_id[pix] = it_id;
 
         // ---- lights (:814-920)
         const f3 view_dir = normalize3(-rd);
