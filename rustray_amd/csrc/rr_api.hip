@@ -70,7 +70,7 @@ struct rr_scene {
     int n_cus = 256;
     std::mutex mu;
     // scene data
-    DevBuf items, nodes, nodes4, tris, attrs, face_slot, materials, textures, texels, lights;
+    DevBuf items, nodes, nodes4, tris, trix, attrs, face_slot, materials, textures, texels, lights;
     DSceneView view{};
     std::vector<DItem> h_items;
     uint32_t n_enabled_lights = 0;
@@ -407,6 +407,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     std::vector<DNode> all_nodes;
     std::vector<DNode4> all_nodes4;
     std::vector<DTri> all_tris;
+    std::vector<DTriX> all_trix;
     std::vector<DTriAttr> all_attrs;
     std::vector<uint32_t> all_face_slot;
     for (uint32_t mi = 0; mi < fs->n_meshes; mi++) {
@@ -452,6 +453,16 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
             t.v1 = make_float4(b[0], b[1], b[2], 0.0f);
             t.v2 = make_float4(c[0], c[1], c[2], 0.0f);
             all_tris.push_back(t);
+            {   // the sequence ray_triangle evaluated per test: ab = b - a, ac = c - a, n = cross3(ab, ac) (rr_math.h)
+                const float ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+                const float nx = ab[1] * ac[2] - ab[2] * ac[1], ny = ab[2] * ac[0] - ab[0] * ac[2], nz = ab[0] * ac[1] - ab[1] * ac[0];
+                DTriX x;
+                x.t0 = t.v0;
+                x.t1 = make_float4(ab[0], ab[1], ab[2], nx);
+                x.t2 = make_float4(ac[0], ac[1], ac[2], ny);
+                x.t3 = make_float4(nz, 0.0f, 0.0f, 0.0f);
+                all_trix.push_back(x);
+            }
             DTriAttr at;
             float n[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, uv[3][2] = {{0, 0}, {0, 0}, {0, 0}};
             if (md[mi].has_normals)
@@ -529,12 +540,13 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     HIP_TRY(upload(s->nodes, all_nodes.data(), all_nodes.size() * sizeof(DNode)));
     HIP_TRY(upload(s->nodes4, all_nodes4.data(), all_nodes4.size() * sizeof(DNode4)));
     HIP_TRY(upload(s->tris, all_tris.data(), all_tris.size() * sizeof(DTri)));
+    HIP_TRY(upload(s->trix, all_trix.data(), all_trix.size() * sizeof(DTriX)));
     HIP_TRY(upload(s->attrs, all_attrs.data(), all_attrs.size() * sizeof(DTriAttr)));
     HIP_TRY(upload(s->face_slot, all_face_slot.data(), all_face_slot.size() * 4));
     HIP_TRY(upload(s->items, s->h_items.data(), s->h_items.size() * sizeof(DItem)));
 
     DSceneView& v = s->view;
-    v.items = s->items.as<DItem>(); v.nodes = s->nodes.as<DNode>(); v.nodes4 = s->nodes4.as<DNode4>(); v.tris = s->tris.as<DTri>(); v.attrs = s->attrs.as<DTriAttr>();
+    v.items = s->items.as<DItem>(); v.nodes = s->nodes.as<DNode>(); v.nodes4 = s->nodes4.as<DNode4>(); v.tris = s->tris.as<DTri>(); v.trix = s->trix.as<DTriX>(); v.attrs = s->attrs.as<DTriAttr>();
     v.face_slot = s->face_slot.as<uint32_t>();
     v.materials = s->materials.as<DMaterial>(); v.textures = s->textures.as<DTexture>(); v.texels = s->texels.as<uint32_t>();
     v.lights = s->lights.as<DLight>();

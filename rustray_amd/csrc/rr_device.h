@@ -36,6 +36,12 @@ struct DNode4 { float4 q[8]; };
 //   v0 = (a.xyz, bits(original face index)), v1 = (b.xyz, 0), v2 = (c.xyz, 0)
 struct DTri { float4 v0, v1, v2; };
 
+// The same triangle as the walks test it, 64 B, same order: the edge vectors and the plane normal of parry's
+// ray/triangle test are the same IEEE values for every ray, so the host computes them once.
+//   t0 = (a.xyz, bits(original face index)), t1 = (ab.xyz, n.x), t2 = (ac.xyz, n.y), t3 = (n.z, 0, 0, 0)
+// with ab = b - a, ac = c - a, n = cross(ab, ac) evaluated exactly as ray_triangle used to (no contraction).
+struct DTriX { float4 t0, t1, t2, t3; };
+
 // Per-triangle shading attributes, 64 B, same order as DTri (fetched once per shaded hit):
 //   s0 = (n0.xyz, uv0.x) s1 = (n1.xyz, uv0.y) s2 = (n2.xyz, uv1.x) s3 = (uv1.y, uv2.x, uv2.y, bits(flags))
 // flags bit0: the reference's get_uv finds uv indices for this face (src/shape/mesh.rs:116)
@@ -96,7 +102,8 @@ struct DSceneView {
     const DItem* items;
     const DNode* nodes;     // all BLAS nodes (BVH2 build), then the TLAS nodes
     const DNode4* nodes4;   // per-mesh trees collapsed to BVH4 (RR_BVH4 builds); DItem::node_base4 / root4 index it
-    const DTri* tris;
+    const DTri* tris;       // vertices, for shading
+    const DTriX* trix;      // the walks' form
     const DTriAttr* attrs;
     const uint32_t* face_slot; // per mesh triangle: original face index -> leaf-order slot
     const DMaterial* materials;

@@ -92,12 +92,11 @@ RR_DEV bool aabb_cast(const float* mins, const float* maxs, const LRay& ray, boo
 // Written with a single exit: every arithmetic result is the same IEEE value as in parry's two branches
 // (v = -ac.e | ac.e, w = ab.e | -ab.e, toi = -t/d | t/d; negation is exact), rejections keep parry's
 // comparison forms so NaNs fall through exactly as they do there; the division runs for accepted hits only.
-RR_DEV bool ray_triangle(f3 a, f3 b, f3 c, const LRay& ray, float* toi_out, uint32_t* side_out) {
+RR_DEV bool ray_triangle(f3 a, f3 ab, f3 ac, f3 n, const LRay& ray, float* toi_out, uint32_t* side_out) {
 #ifdef RR_ABLATE_TRI
     if (a.x != 123.456f) return false; // timing experiment: triangles are fetched but never tested
 #endif
-    const f3 ab = b - a, ac = c - a;
-    const f3 n = cross3(ab, ac);
+    // ab = b - a, ac = c - a, n = cross3(ab, ac): computed once per triangle on the host (DTriX)
     const float d = dot3(n, ray.d);
     const f3 ap = ray.o - a;
     const float t = dot3(ap, n);
@@ -317,11 +316,11 @@ struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool foun
         const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);                               \
         for (uint32_t i = 0; i < count; i++) {                                                                 \
             RR_UTIL(3)                                                                                         \
-            const DTri tr = tris[first + i];                                                                   \
+            const DTriX tr = tris[first + i];                                                                  \
             float t; uint32_t side;                                                                            \
-            if (ray_triangle(mk3(tr.v0.x, tr.v0.y, tr.v0.z), mk3(tr.v1.x, tr.v1.y, tr.v1.z),                   \
-                             mk3(tr.v2.x, tr.v2.y, tr.v2.z), ray, &t, &side)) {                                \
-                const uint32_t face = __float_as_uint(tr.v0.w);                                                \
+            if (ray_triangle(mk3(tr.t0.x, tr.t0.y, tr.t0.z), mk3(tr.t1.x, tr.t1.y, tr.t1.z),                   \
+                             mk3(tr.t2.x, tr.t2.y, tr.t2.z), mk3(tr.t1.w, tr.t2.w, tr.t3.x), ray, &t, &side)) { \
+                const uint32_t face = __float_as_uint(tr.t0.w);                                                \
                 if (!best.found || t < best.t || (t == best.t && face < best.face)) {                          \
                     best.found = true; best.t = t; best.slot = first + i; best.face = face; best.side = side;  \
                 }                                                                                              \
@@ -334,10 +333,10 @@ struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool foun
         const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);                               \
         for (uint32_t i = 0; i < count; i++) {                                                                 \
             RR_UTIL(3)                                                                                         \
-            const DTri tr = tris[first + i];                                                                   \
+            const DTriX tr = tris[first + i];                                                                  \
             float t; uint32_t side;                                                                            \
-            if (ray_triangle(mk3(tr.v0.x, tr.v0.y, tr.v0.z), mk3(tr.v1.x, tr.v1.y, tr.v1.z),                   \
-                             mk3(tr.v2.x, tr.v2.y, tr.v2.z), ray, &t, &side)) {                                \
+            if (ray_triangle(mk3(tr.t0.x, tr.t0.y, tr.t0.z), mk3(tr.t1.x, tr.t1.y, tr.t1.z),                   \
+                             mk3(tr.t2.x, tr.t2.y, tr.t2.z), mk3(tr.t1.w, tr.t2.w, tr.t3.x), ray, &t, &side)) { \
                 any = true;                                                                                    \
                 if (t <= limit) within = true;                                                                 \
             }                                                                                                  \
@@ -349,7 +348,7 @@ RR_DEV void blas_closest(const DSceneView& sc, const DItem& it, const LRay& ray,
     TriBest best; best.found = false; best.t = RR_FLT_MAX; best.slot = 0; best.face = 0xffffffffu; best.side = 0u;
     const BlasSlab sr = RR_BLAS_SLAB(ray);
     const BlasNode* nodes = RR_BLAS_NODES(sc, it);
-    const DTri* tris = sc.tris + it.tri_base;
+    const DTriX* tris = sc.trix + it.tri_base;
     int sp = sp_base;
     STK(sp) = RR_SENTINEL; sp++;
     int cur = RR_BLAS_ROOT(it);
@@ -390,7 +389,7 @@ RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, flo
     bool any = false, within = false;
     const BlasSlab sr = RR_BLAS_SLAB(ray);
     const BlasNode* nodes = RR_BLAS_NODES(sc, it);
-    const DTri* tris = sc.tris + it.tri_base;
+    const DTriX* tris = sc.trix + it.tri_base;
     int sp = sp_base;
     STK(sp) = RR_SENTINEL; sp++;
     int cur = RR_BLAS_ROOT(it);
