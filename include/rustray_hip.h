@@ -234,6 +234,8 @@ typedef struct rr_frame_stats {
     uint64_t launches_trace_closest;
     uint64_t launches_trace_shadow;
     uint64_t launches_shade;
+    uint64_t batches;       /* device batches of primary samples the frame was cut into */
+    uint64_t sliced_levels; /* depth levels whose children did not fit behind them in the ray arena at once */
 } rr_frame_stats;
 
 typedef struct rr_scene rr_scene; /* opaque */

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -76,8 +77,9 @@ struct rr_scene {
     uint32_t n_enabled_lights = 0;
     uint32_t tlas_node_capacity = 0;
     // frame state (grown on demand, reused across frames)
-    DevBuf q[2][4];   // r0 r1 r2 hit
-    size_t q_cap[2] = {0, 0};
+    DevBuf arena[4];  // ray records of all live depth levels, SoA: r0 r1 r2 hit
+    size_t arena_cap = 0; // rays
+    uint32_t arena_factor = 3; // arena rays per primary ray of a batch; doubled after a frame that had to slice levels
     DevBuf sq[4];
     size_t sq_cap = 0;
     DevBuf acc_rgb, acc_normal, acc_depth, acc_id;
@@ -571,7 +573,7 @@ extern "C" void rr_scene_destroy(rr_scene* s) {
     DevBuf* all[] = {&s->items, &s->nodes, &s->tris, &s->attrs, &s->face_slot, &s->materials, &s->textures, &s->texels, &s->lights,
                      &s->acc_rgb, &s->acc_normal, &s->acc_depth, &s->acc_id, &s->region_xy, &s->trace_order, &s->sample_xy, &s->pool, &s->counters};
     for (DevBuf* b : all) b->release();
-    for (int i = 0; i < 2; i++) for (int k = 0; k < 4; k++) s->q[i][k].release();
+    for (int k = 0; k < 4; k++) s->arena[k].release();
     for (int k = 0; k < 4; k++) { s->sq[k].release(); s->tmp_out[k].release(); }
     for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
     for (auto& t : s->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -725,106 +727,139 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     if (!out->depth) acc.depth = nullptr;
     if (!out->object_id) acc.object_id = nullptr;
 
-    // ---- batch sizing.  Level d (1-based depth) holds at most B * 2^(d-1) rays, d <= max_recursion + 1;
-    // odd levels live in queue 0, even levels in queue 1.
+    // ---- ray memory.  All live depth levels of a batch sit in ONE arena of ray records (56 B each), level d + 1
+    // stacked behind level d.  A level of n rays spawns at most 2 n children; if they fit behind it the level is
+    // shaded in one go, otherwise in slices whose children fit, each slice's subtree finished (depth first) before
+    // the next slice starts.  So capacity never limits correctness, only how large the launches can be -- and launch
+    // size matters: the persistent trace kernels lose 8-15 % to ramp-up and tail per launch at 12 M rays
+    // (reserving the worst case 2^(d-1) growth per level, as the first version did, capped batches there).
     const uint32_t R = cfg->max_recursion;
-    uint64_t f_odd = 1, f_even = 0;
-    for (uint32_t d = 1; d <= R + 1; d++) { uint64_t f = 1ull << (d - 1); if (d & 1) f_odd = std::max(f_odd, f); else f_even = std::max(f_even, f); }
-    // Queue memory: a quarter of what is free on the device, at most 64 GB (MI355X has 288 GB of HBM3E),
-    // unless RR_QUEUE_BUDGET_MB says otherwise.  Memory already held by this scene's queues counts as free.
+    // Arena memory: a quarter of what is free on the device, at most 64 GB (MI355X has 288 GB of HBM3E),
+    // unless RR_QUEUE_BUDGET_MB says otherwise.  Memory already held by this scene's arena counts as free.
     const char* env_budget = getenv("RR_QUEUE_BUDGET_MB");
     uint64_t budget;
     if (env_budget) budget = (uint64_t)atoll(env_budget) << 20;
     else {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        uint64_t held = 56ull * (s->q_cap[0] + s->q_cap[1]);
-        budget = std::min<uint64_t>((free_b + held) / 4, 64ull << 30);
+        budget = std::min<uint64_t>((free_b + 56ull * s->arena_cap) / 4, 64ull << 30);
     }
     const uint64_t total_primary = (uint64_t)npix * cfg->samples;
-    uint64_t B = budget / (56ull * (f_odd + f_even));
-    B = std::max<uint64_t>(B, 4096);
-    B = std::min<uint64_t>(B, total_primary);
-    B = std::min<uint64_t>(B, 0x7fffffffull / std::max<uint64_t>(f_odd, 1));
+    const uint64_t LEVEL_MAX = 0x7fffff00ull; // ray indices are 32-bit
+    // a batch of B primary rays gets an arena of 3 B: enough for every level of a typical frame at once
+    // (sponza_syn: all deeper levels together hold 4 % of the primaries), sliced when a scene branches more
+    uint64_t B = std::max<uint64_t>(budget / 56ull / 3ull, 4096);
+    B = std::min<uint64_t>(B, std::min<uint64_t>(total_primary, LEVEL_MAX / 3));
     if (hook && hook->min_passes > 1) B = std::min<uint64_t>(B, std::max<uint64_t>(npix, (total_primary + hook->min_passes - 1) / hook->min_passes));
     // equal batches (a frame that needs 1.2 batches would otherwise end with a small, poorly filled one)
     { const uint64_t nb = (total_primary + B - 1) / B; B = (total_primary + nb - 1) / nb; }
     if (B > npix) B = ((B + npix - 1) / npix) * npix; // whole sample slices when possible
     B = std::min<uint64_t>(B, total_primary);
-    const uint64_t cap[2] = {B * f_odd, std::max<uint64_t>(B * f_even, 1)};
+    const uint64_t M = std::min<uint64_t>(std::min<uint64_t>((uint64_t)s->arena_factor * B, std::max<uint64_t>(3 * B, budget / 56ull)) + 2ull * RR_BLOCK * (R + 1), LEVEL_MAX);
     const size_t elem[4] = {16, 16, 8, 16};
-    for (int i = 0; i < 2; i++)
-        if (cap[i] > s->q_cap[i]) {
-            for (int k = 0; k < 4; k++) HIP_TRY(s->q[i][k].reserve(cap[i] * elem[k]));
-            s->q_cap[i] = cap[i];
-        }
+    if (M > s->arena_cap) {
+        for (int k = 0; k < 4; k++) HIP_TRY(s->arena[k].reserve(M * elem[k]));
+        s->arena_cap = M;
+    }
     const char* env_chunk = getenv("RR_SHADE_CHUNK");
-    const uint64_t chunk = env_chunk ? std::max<uint64_t>(65536, (uint64_t)atoll(env_chunk)) : (4ull << 20);
-    const uint64_t sq_need = std::max<uint64_t>(1, (std::min<uint64_t>(chunk, cap[0]) + RR_BLOCK * RR_SQ_SHARDS) * std::max<uint32_t>(s->n_enabled_lights, 1u));
+    const uint64_t chunk = env_chunk ? std::max<uint64_t>(65536, (uint64_t)atoll(env_chunk)) : (32ull << 20);
+    const uint64_t sq_need = std::max<uint64_t>(1, (std::min<uint64_t>(chunk, M) + RR_BLOCK * RR_SQ_SHARDS) * std::max<uint32_t>(s->n_enabled_lights, 1u));
     if (sq_need > s->sq_cap) {
         for (int k = 0; k < 4; k++) HIP_TRY(s->sq[k].reserve(sq_need * 16));
         s->sq_cap = sq_need;
     }
-    DRayQueue Q[2];
-    for (int i = 0; i < 2; i++) { Q[i].r0 = s->q[i][0].as<float4>(); Q[i].r1 = s->q[i][1].as<float4>(); Q[i].r2 = s->q[i][2].as<uint2>(); Q[i].hit = s->q[i][3].as<uint4>(); }
+    auto queue_at = [&](uint64_t base) {
+        DRayQueue q;
+        q.r0 = s->arena[0].as<float4>() + base; q.r1 = s->arena[1].as<float4>() + base;
+        q.r2 = s->arena[2].as<uint2>() + base; q.hit = s->arena[3].as<uint4>() + base;
+        return q;
+    };
     DShadowQueue SQ{s->sq[0].as<float4>(), s->sq[1].as<float4>(), s->sq[2].as<float4>(), s->sq[3].as<uint4>()};
 
     uint32_t* pool = s->pool.as<uint32_t>();
     unsigned long long* counters = s->counters.as<unsigned long long>();
     const int trace_grid = s->n_cus * RR_TRACE_WAVES; // RR_STACK_DEPTH KB of LDS stack per 256-thread workgroup
     const int shade_grid_max = s->n_cus * 2 * RR_SHADE_WAVES;
+    const uint32_t L = s->n_enabled_lights;
 
-    HIP_TRY(hipEventRecord(s->frame_a, st));
-    for (uint64_t first = 0; first < total_primary; first += B) {
-        if (cancel && *cancel) { (void)hipStreamSynchronize(st); return fail(RR_ERR_CANCELLED, "cancelled"); }
-        const uint32_t n_batch = (uint32_t)std::min<uint64_t>(B, total_primary - first);
-        uint32_t next_word = 0;
-        auto word = [&]() -> uint32_t* { return pool + (next_word++); };
-        HIP_TRY(hipMemsetAsync(pool, 0, POOL_WORDS * 4, st));
-        // level counts live in the first words of the pool
-        uint32_t* level_count = pool; next_word = R + 4;
-        // The batch covers primary indices [first, first + n_batch): index i -> sample i / npix, pixel i % npix.
-        hipLaunchKernelGGL(k_raygen, dim3((n_batch + RR_BLOCK - 1) / RR_BLOCK), dim3(RR_BLOCK), 0, st, fr, s->region_xy.as<uint32_t>(),
-                           s->sample_xy.as<uint16_t>(), (unsigned long long)first, n_batch, Q[0], &level_count[1], counters);
-        // Depth levels.  The size of the next level is read back once per level (one 4-byte copy + stream
-        // sync): launches are then sized by the rays that exist, and empty levels are never launched.
-        uint64_t n_level = n_batch;
-        for (uint32_t d = 1; d <= R + 1 && n_level > 0; d++) {
-            const DRayQueue& qin = Q[(d - 1) & 1];
-            const DRayQueue& qout = Q[d & 1];
-            {
-                ScopedTimer t(s, st, 0);
-                const int grid = (int)std::min<uint64_t>((n_level + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)trace_grid);
-                hipLaunchKernelGGL(k_trace_closest, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, qin, &level_count[d], word());
-            }
-            for (uint64_t c0 = 0; c0 < n_level; c0 += chunk) {
-                const uint64_t c1 = std::min<uint64_t>(c0 + chunk, n_level);
-                if (next_word + 3 >= POOL_WORDS) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise RR_SHADE_CHUNK");
+    uint32_t next_word = 0;
+    auto words = [&](uint32_t n) -> uint32_t* {
+        if (next_word + n > POOL_WORDS) return nullptr;
+        uint32_t* p = pool + next_word; next_word += n; return p;
+    };
+    // One depth level: rays [base, base + n) of the arena, their count also in the device word `count`.
+    // The size of the next level is read back once per slice (4 bytes + stream sync), so launches are sized by the
+    // rays that exist and empty levels are never launched.
+    std::function<int(uint32_t, uint64_t, uint64_t, const uint32_t*)> run_level =
+        [&](uint32_t d, uint64_t base, uint64_t n, const uint32_t* count) -> int {
+        const DRayQueue qin = queue_at(base);
+        {
+            uint32_t* head = words(1);
+            if (!head) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise RR_SHADE_CHUNK");
+            ScopedTimer t(s, st, 0);
+            const int grid = (int)std::min<uint64_t>((n + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)trace_grid);
+            hipLaunchKernelGGL(k_trace_closest, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, qin, count, head);
+        }
+        const bool spawns = d <= R; // the deepest level spawns nothing (k_shade: depth <= max_recursion)
+        const uint64_t child_base = base + n;
+        // Children of a slice may use the space behind this level minus what the deeper levels need to make progress
+        // themselves (one 256-ray slice = 512 children per spawning level below): the recursion can then never get stuck.
+        uint64_t slice = n;
+        if (spawns) {
+            const uint64_t keep = 2ull * RR_BLOCK * (R - d); // spawning levels below d + 1's parent: d + 1 .. R
+            const uint64_t room = M - child_base;
+            if (room < keep + 2ull * RR_BLOCK) return fail(RR_ERR_OUT_OF_MEMORY, "ray arena of %llu rays is too small for depth level %u", (unsigned long long)M, d);
+            if (2 * n > room - keep) { slice = ((room - keep) / 2 / RR_BLOCK) * RR_BLOCK; s->stats.sliced_levels++; }
+        }
+        for (uint64_t s0 = 0; s0 < n; s0 += slice) {
+            const uint64_t s1 = std::min<uint64_t>(s0 + slice, n);
+            uint32_t* child_count = words(1);
+            if (!child_count) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise RR_SHADE_CHUNK");
+            const DRayQueue qout = queue_at(child_base);
+            for (uint64_t c0 = s0; c0 < s1; c0 += chunk) {
+                const uint64_t c1 = std::min<uint64_t>(c0 + chunk, s1);
                 const int grid = (int)std::min<uint64_t>((c1 - c0 + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)shade_grid_max);
-                const uint32_t L = s->n_enabled_lights;
                 // shadow sub-queues: a shard gets the packets with (packet % RR_SQ_SHARDS == shard), L rays per hit at most
                 const uint64_t groups = (c1 - c0 + RR_BLOCK - 1) / RR_BLOCK; // 256-ray groups, dealt round-robin to the shards
                 const uint32_t segcap = (uint32_t)(((groups + RR_SQ_SHARDS - 1) / RR_SQ_SHARDS) * RR_BLOCK * std::max(L, 1u));
-                if (next_word + RR_SQ_SHARDS + 2 >= POOL_WORDS) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise RR_SHADE_CHUNK");
-                uint32_t* sq_counts = pool + next_word; next_word += RR_SQ_SHARDS;
+                uint32_t* sq_counts = words(RR_SQ_SHARDS);
+                uint32_t* shead = words(1);
+                if (!sq_counts || !shead) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise RR_SHADE_CHUNK");
                 {
                     ScopedTimer t(s, st, 2);
-                    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, fr, s->region_xy.as<uint32_t>(), qin, &level_count[d],
-                                       (uint32_t)c0, (uint32_t)c1, qout, &level_count[d + 1], SQ, sq_counts, segcap, acc, counters);
+                    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, fr, s->region_xy.as<uint32_t>(), qin, count,
+                                       (uint32_t)c0, (uint32_t)c1, qout, child_count, SQ, sq_counts, segcap, acc, counters);
                 }
                 if (L) {
                     ScopedTimer t(s, st, 1);
                     const uint64_t sq_ub = (c1 - c0) * L;
                     const int sgrid = (int)std::min<uint64_t>((sq_ub + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)trace_grid);
-                    hipLaunchKernelGGL(k_trace_shadow, dim3(sgrid), dim3(RR_BLOCK), 0, st, s->view, SQ, sq_counts, segcap, word(), acc);
+                    hipLaunchKernelGGL(k_trace_shadow, dim3(sgrid), dim3(RR_BLOCK), 0, st, s->view, SQ, sq_counts, segcap, shead, acc);
                 }
             }
-            if (d == R + 1) break; // the deepest level spawns nothing
-            HIP_TRY(hipMemcpyAsync(s->h_count, &level_count[d + 1], 4, hipMemcpyDeviceToHost, st));
+            if (!spawns) continue;
+            HIP_TRY(hipMemcpyAsync(s->h_count, child_count, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            n_level = *s->h_count;
-            if (n_level > cap[d & 1]) return fail(RR_ERR_DEVICE, "internal: level %u holds %llu rays, capacity %llu", d + 1, (unsigned long long)n_level, (unsigned long long)cap[d & 1]);
+            const uint64_t m = *s->h_count;
+            if (m > M - child_base) return fail(RR_ERR_DEVICE, "internal: level %u holds %llu rays, room for %llu", d + 1, (unsigned long long)m, (unsigned long long)(M - child_base));
+            if (m > 0) { const int rc2 = run_level(d + 1, child_base, m, child_count); if (rc2 != RR_OK) return rc2; }
         }
+        return RR_OK;
+    };
+
+    HIP_TRY(hipEventRecord(s->frame_a, st));
+    for (uint64_t first = 0; first < total_primary; first += B) {
+        if (cancel && *cancel) { (void)hipStreamSynchronize(st); return fail(RR_ERR_CANCELLED, "cancelled"); }
+        const uint32_t n_batch = (uint32_t)std::min<uint64_t>(B, total_primary - first);
+        HIP_TRY(hipMemsetAsync(pool, 0, POOL_WORDS * 4, st));
+        next_word = 0;
+        uint32_t* level1_count = words(1);
+        // The batch covers primary indices [first, first + n_batch): index i -> sample i / npix, pixel i % npix.
+        hipLaunchKernelGGL(k_raygen, dim3((n_batch + RR_BLOCK - 1) / RR_BLOCK), dim3(RR_BLOCK), 0, st, fr, s->region_xy.as<uint32_t>(),
+                           s->sample_xy.as<uint16_t>(), (unsigned long long)first, n_batch, queue_at(0), level1_count, counters);
+        s->stats.batches++;
+        const int rcl = run_level(1, 0, n_batch, level1_count);
+        if (rcl != RR_OK) return rcl;
         HIP_TRY(hipGetLastError());
         // batches are stream-ordered; only a caller that can cancel needs the host to keep pace with the device
         if (cancel && first + B < total_primary) HIP_TRY(hipStreamSynchronize(st));
@@ -845,6 +880,8 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
                        out->rgba8, out->normal, out->depth, out->object_id, frame_layout ? 1u : 0u);
     HIP_TRY(hipEventRecord(s->frame_b, st));
     HIP_TRY(hipGetLastError());
+    // a scene that branches more than the arena was sized for gets a larger one for its next frame (within the budget)
+    if (s->stats.sliced_levels > 0 && s->arena_factor < 128) s->arena_factor *= 2;
     return RR_OK;
 }
 

@@ -112,7 +112,7 @@ class rr_frame_stats(C.Structure):
         ("shaded_hits", C.c_uint64), ("ms_total", C.c_double), ("ms_trace_closest", C.c_double),
         ("ms_trace_shadow", C.c_double), ("ms_shade", C.c_double),
         ("launches_trace_closest", C.c_uint64), ("launches_trace_shadow", C.c_uint64),
-        ("launches_shade", C.c_uint64),
+        ("launches_shade", C.c_uint64), ("batches", C.c_uint64), ("sliced_levels", C.c_uint64),
     ]
 
 

@@ -132,15 +132,57 @@ def test_batching_and_chunking_do_not_change_a_single_bit(hip, monkeypatch):
     cam = camera_for(fs, 96, 54).c_struct()
     cfg = make_config(samples=6, monte_carlo=True, seed=33)
     outs = []
-    for budget, chunk in (("16384", None), ("4", "65536"), ("1", "65536")):
+    stats = []
+    for budget, chunk in (("16384", None), ("4", "65536"), ("1", "65536"), ("0", "65536")):
         monkeypatch.setenv("RR_QUEUE_BUDGET_MB", budget)
         if chunk:
             monkeypatch.setenv("RR_SHADE_CHUNK", chunk)
         with hip.DeviceScene(fs, 0) as ds:
             outs.append(ds.render(cam, cfg))
+            stats.append(ds.stats())
+    assert stats[0]["batches"] == 1 and stats[-1]["batches"] > 4
     for o in outs[1:]:
         assert (o["rgba"] == outs[0]["rgba"]).all() and np.array_equal(o["depth"], outs[0]["depth"])
         assert np.array_equal(o["normal"], outs[0]["normal"], equal_nan=True) and (o["object_id"] == outs[0]["object_id"]).all()
+
+
+def test_branching_scene_in_a_small_ray_arena_is_sliced_depth_first(hip, monkeypatch):
+    """Every hit on glass spawns two children; with a ray arena of a few thousand rays the deeper levels do not fit
+    behind their parents at once, so levels are shaded in slices whose subtrees finish first (rr_api.hip run_level).
+    Same bits as the unconstrained frame."""
+    from rustray_amd.flat import FlatScene, Item, Light, Material
+    from rustray_amd.scene import Scene
+    fs = FlatScene()
+    eye4 = np.eye(4, dtype=np.float32)
+    for i, (x, y, z, r) in enumerate([(0, 0, -6, 2.0), (2.5, 0.5, -8, 2.0), (-2.5, -0.5, -8, 2.0), (0, 2.5, -9, 2.0), (0, -3, -7, 2.0)]):
+        m = Material(base_color=(0.2 + 0.15 * i, 0.5, 0.9 - 0.15 * i), alpha=0.4, reflectivity=0.5, refraction_index=1.4)
+        fs.materials.append(m); fs.materials.append(Scene._cache_of(m))
+        t = eye4.copy(); t[:3, 3] = (x, y, z)
+        ti = eye4.copy(); ti[:3, 3] = (-x, -y, -z)
+        fs.items.append(Item(kind=0, id=i + 1, material=2 * i, material_cache=2 * i + 1, radius=r, trans=t, trans_inv=ti,
+                             bbox_min=(-r, -r, -r), bbox_max=(r, r, r), name=f"glass{i}"))
+    fs.lights = [Light(pos=(3.0, 6.0, 2.0), intensity=150.0)]
+    fs.meta = {"camera": dict(width=64, height=64, fov=float(np.float32(np.radians(70.0))), eye_pos=[0.0, 0.0, 0.0], up=[0.0, 1.0, 0.0],
+                              dir=[0.0, 0.0, -1.0], clipping_near=0.1, clipping_far=100.0)}
+    cam = camera_for(fs, 96, 96).c_struct()
+    cfg = make_config(samples=2, monte_carlo=False, seed=1, max_recursion=6)
+    with hip.DeviceScene(fs, 0) as ds:
+        first = ds.render(cam, cfg)
+        st_first = ds.stats()
+        for _ in range(3):   # a frame that had to slice doubles the arena of the next one
+            ref = ds.render(cam, cfg)
+        st0 = ds.stats()
+    assert st_first["sliced_levels"] > 0 and np.array_equal(first["rgba"], ref["rgba"])
+    monkeypatch.setenv("RR_QUEUE_BUDGET_MB", "0")
+    monkeypatch.setenv("RR_SHADE_CHUNK", "65536")
+    with hip.DeviceScene(fs, 0) as ds:
+        out = ds.render(cam, cfg)
+        st = ds.stats()
+    assert st0["sliced_levels"] == 0 and st["sliced_levels"] > 0 and st["batches"] > 1
+    assert st["secondary_rays"] == st0["secondary_rays"] > 3 * st["primary_rays"]
+    for k in ("rgba", "depth", "object_id"):
+        assert np.array_equal(out[k], ref[k]), k
+    assert np.array_equal(out["normal"], ref["normal"], equal_nan=True)
 
 
 def test_tiled_regions_reassemble_bit_exactly(hip):
