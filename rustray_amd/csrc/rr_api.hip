@@ -762,7 +762,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         s->arena_cap = M;
     }
     const char* env_chunk = getenv("RR_SHADE_CHUNK");
-    const uint64_t chunk = env_chunk ? std::max<uint64_t>(65536, (uint64_t)atoll(env_chunk)) : (32ull << 20);
+    const uint64_t chunk = env_chunk ? std::max<uint64_t>(65536, (uint64_t)atoll(env_chunk)) : (64ull << 20);
     const uint64_t sq_need = std::max<uint64_t>(1, (std::min<uint64_t>(chunk, M) + RR_BLOCK * RR_SQ_SHARDS) * std::max<uint32_t>(s->n_enabled_lights, 1u));
     if (sq_need > s->sq_cap) {
         for (int k = 0; k < 4; k++) HIP_TRY(s->sq[k].reserve(sq_need * 16));

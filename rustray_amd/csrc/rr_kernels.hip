@@ -29,6 +29,10 @@
 #define RR_TRACE_WAVES 4 // waves per SIMD the trace kernels are built for (bounds VGPRs; LDS stack: RR_STACK_DEPTH KB per workgroup)
 #endif
 #define RR_WAVE 64
+#ifndef RR_SHADOW_STATIC_NUM
+#define RR_SHADOW_STATIC_NUM 3
+#define RR_SHADOW_STATIC_DEN 4
+#endif
 
 __constant__ float c_u8_to_f32[256]; // i / 255.0f, exactly as `(p[0] as f32) / 255.0`
 
@@ -1282,11 +1286,25 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DScen
     const uint32_t lane = threadIdx.x & (RR_WAVE - 1);
     const bool gw = sc.general_w != 0u;
     const uint32_t n_packets = (n + RR_WAVE - 1) / RR_WAVE;
+    // same packet stream as k_trace_closest: most packets dealt round-robin without an atomic (blocks of one XCD
+    // take one contiguous run per round), the tail pulled one packet at a time to absorb the expensive ones
+    const uint32_t n_waves = gridDim.x * (RR_BLOCK / RR_WAVE);
+    uint32_t blk = blockIdx.x;
+#ifndef RR_NO_XCD_SWIZZLE
+    if ((gridDim.x & 7u) == 0u) blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#endif
+    const uint32_t wave_id = blk * (RR_BLOCK / RR_WAVE) + threadIdx.x / RR_WAVE;
+    const uint32_t rounds = (uint32_t)(((unsigned long long)n_packets * RR_SHADOW_STATIC_NUM / RR_SHADOW_STATIC_DEN) / n_waves);
+    const uint32_t n_static = rounds * n_waves;
+    uint32_t round = 0;
     for (;;) {
-        // shadow rays differ a lot in cost (early exit vs full walk): one packet per fetch balances best
-        uint32_t p = 0;
-        if (lane == 0) p = atomicAdd(head, 1u);
-        p = __shfl(p, 0);
+        uint32_t p;
+        if (round < rounds) { p = round * n_waves + wave_id; round++; }
+        else {
+            uint32_t f = 0;
+            if (lane == 0) f = atomicAdd(head, 1u);
+            p = n_static + __shfl(f, 0);
+        }
         if (p >= n_packets) break;
         {
         const uint32_t j = p * RR_WAVE + lane;
