@@ -881,14 +881,24 @@ RR_DEV float4 mat4_mul(const float* m, float x, float y, float z, float w) {
 
 __global__ __launch_bounds__(RR_BLOCK) void k_raygen(DFrame fr, const uint32_t* __restrict__ slot_xy,
                                                      const uint16_t* __restrict__ sample_xy,
-                                                     unsigned long long first, uint32_t n_rays, DRayQueue q,
+                                                     unsigned long long first, uint32_t n_rays, uint32_t group, DRayQueue q,
                                                      uint32_t* q_count, unsigned long long* counters) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) { *q_count = n_rays; atomicAdd(&counters[RR_CNT_PRIMARY], (unsigned long long)n_rays); }
     if (i >= n_rays) return;
-    const unsigned long long gi = first + i; // sample-major index over the region: sample = gi / n_pix
-    uint32_t pix = (uint32_t)(gi % fr.n_region_pixels); // accumulator slot: slots enumerate 8x8 blocks of the region's tiles
-    uint32_t s = (uint32_t)(gi / fr.n_region_pixels);
+    uint32_t pix, s; // accumulator slot (slots enumerate 8x8 blocks of the region's tiles) and sample
+    if (group <= 1u) {
+        const unsigned long long gi = first + i; // sample-major index over the region: sample = gi / n_pix
+        pix = (uint32_t)(gi % fr.n_region_pixels);
+        s = (uint32_t)(gi / fr.n_region_pixels);
+    } else {
+        // a 64-ray packet = 64/group neighbouring pixels x `group` samples of each (the host guarantees whole groups)
+        const uint32_t ppp = RR_WAVE / group;                       // pixels per packet
+        const uint32_t packets_per_group = fr.n_region_pixels / ppp;
+        const uint32_t pkt = i / RR_WAVE, lane = i % RR_WAVE;
+        pix = (pkt % packets_per_group) * ppp + lane % ppp;
+        s = (uint32_t)(first / fr.n_region_pixels) + (pkt / packets_per_group) * group + lane / ppp;
+    }
     uint32_t xy = slot_xy[pix];
     float x_f = (float)(xy & 0xffffu), y_f = (float)(xy >> 16);
     float w = (float)fr.width, h = (float)fr.height;
