@@ -756,12 +756,13 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     if (B > npix) B = ((B + npix - 1) / npix) * npix; // whole sample slices when possible
     // Sample grouping: a packet of 64 primary rays = 64/G neighbouring pixels x G samples of each (k_raygen), so the
     // rays of a wave - and the shadow rays and children they spawn - start almost identical and their walks stay
-    // together.  G = 16 measured best (closest-hit -21 % on sponza_syn against one sample of 64 pixels; at 32 and 64
-    // the accumulator atomics of a wave pile up on too few addresses).  Needs whole groups per batch.
+    // together.  The largest group the sample count allows is best (closest-hit -30 % on sponza_syn at G = 64 against
+    // one sample of 64 pixels), given that the wave merges its accumulator adds per pixel first (accum_merged): 64
+    // lanes adding to one address otherwise cost more than the walks gain.  Needs whole groups per batch.
     uint32_t G = 1;
     {
         static const uint32_t forced = getenv("RR_SPP_GROUP") ? (uint32_t)atoi(getenv("RR_SPP_GROUP")) : 0u; // developer knob
-        for (uint32_t g = forced ? forced : 16u; g >= 2; g >>= 1)
+        for (uint32_t g = forced ? forced : 64u; g >= 2; g >>= 1)
             if (g <= 64 && !(g & (g - 1)) && cfg->samples % g == 0 && npix % (RR_WAVE / g) == 0 && (uint64_t)npix * g <= B) { G = g; break; }
         if (forced && G != forced) G = 1;
     }

@@ -835,17 +835,41 @@ RR_DEV long long to_fix(float v, float scale, float clampv) {
     v = fminf(fmaxf(v, -clampv), clampv);
     return __float2ll_rn(v * scale);
 }
-RR_DEV void accum_rgb(const DAccum& acc, uint32_t pix, float r, float g, float b) {
+// Adds of one wave to the accumulators, merged: neighbouring lanes that add to the same pixel (the samples of one
+// pixel sit in neighbouring lanes, k_raygen; compaction keeps lane order) are summed first with a segmented scan over
+// the 16-lane DPP rows, and only the last lane of each run issues the atomics.  Integer adds commute, so the frame
+// is the same whatever is merged.  Must be called by all 64 lanes of the wave; lanes with nothing to add pass
+// pix = 0xffffffff.  (64 lanes adding to one address, or 16, serialise in the L2 atomic units: +10 ms on sponza_syn.)
+#define RR_DPP_SHR(x, n) __builtin_amdgcn_update_dpp(0, (int)(x), 0x110 + (n), 0xf, 0xf, true)
+#define RR_DPP_SHL(x, n) __builtin_amdgcn_update_dpp(0, (int)(x), 0x100 + (n), 0xf, 0xf, true)
+#define RR_SEG_STEP(n)                                                                                         \
+    {                                                                                                          \
+        const int pf = RR_DPP_SHR(f, n);                                                                       \
+        const unsigned long long pr = ((unsigned long long)(uint32_t)RR_DPP_SHR((uint32_t)(vr >> 32), n) << 32) | (uint32_t)RR_DPP_SHR((uint32_t)vr, n); \
+        const unsigned long long pg = ((unsigned long long)(uint32_t)RR_DPP_SHR((uint32_t)(vg >> 32), n) << 32) | (uint32_t)RR_DPP_SHR((uint32_t)vg, n); \
+        const unsigned long long pb = ((unsigned long long)(uint32_t)RR_DPP_SHR((uint32_t)(vb >> 32), n) << 32) | (uint32_t)RR_DPP_SHR((uint32_t)vb, n); \
+        if (!f) { vr += pr; vg += pg; vb += pb; f = pf; }                                                      \
+    }
+RR_DEV void accum_merged(const DAccum& acc, uint32_t pix, long long r, long long g, long long b) {
 #ifdef RR_EXP_NO_ATOMICS
-    if (r == 123.456f) acc.rgb[pix] = 0; // timing experiment only
+    if (r == 123456789ll) acc.rgb[pix] = 0; // timing experiment only
     return;
 #endif
-    long long fr = to_fix(r, RR_FIX_SCALE, RR_FIX_CLAMP), fg = to_fix(g, RR_FIX_SCALE, RR_FIX_CLAMP), fb = to_fix(b, RR_FIX_SCALE, RR_FIX_CLAMP);
-    // one plane per channel: the 64 lanes of a wave of primary rays add to 64 consecutive words (8 x 64-B requests)
-    unsigned long long* p = (unsigned long long*)acc.rgb + pix;
-    if (fr) atomicAdd(p, (unsigned long long)fr);
-    if (fg) atomicAdd(p + acc.n, (unsigned long long)fg);
-    if (fb) atomicAdd(p + 2ull * acc.n, (unsigned long long)fb);
+    const uint32_t lane16 = threadIdx.x & 15u;
+    const uint32_t prev = (uint32_t)RR_DPP_SHR(pix, 1);
+    const int head = (lane16 == 0u || prev != pix) ? 1 : 0; // first lane of a run of equal pixels inside its row
+    int f = head;
+    unsigned long long vr = (unsigned long long)r, vg = (unsigned long long)g, vb = (unsigned long long)b;
+    RR_SEG_STEP(1) RR_SEG_STEP(2) RR_SEG_STEP(4) RR_SEG_STEP(8)
+    const int next_head = RR_DPP_SHL(head, 1);
+    const bool tail = lane16 == 15u || next_head != 0;
+    if (tail && pix != 0xffffffffu) {
+        // one plane per channel
+        unsigned long long* p = (unsigned long long*)acc.rgb + pix;
+        if (vr) atomicAdd(p, vr);
+        if (vg) atomicAdd(p + acc.n, vg);
+        if (vb) atomicAdd(p + 2ull * acc.n, vb);
+    }
 }
 
 // Persistent packet fetch: one atomic per wave hands out RR_FETCH packets of 64 consecutive queue slots.
@@ -896,8 +920,9 @@ __global__ __launch_bounds__(RR_BLOCK) void k_raygen(DFrame fr, const uint32_t* 
         const uint32_t ppp = RR_WAVE / group;                       // pixels per packet
         const uint32_t packets_per_group = fr.n_region_pixels / ppp;
         const uint32_t pkt = i / RR_WAVE, lane = i % RR_WAVE;
-        pix = (pkt % packets_per_group) * ppp + lane % ppp;
-        s = (uint32_t)(first / fr.n_region_pixels) + (pkt / packets_per_group) * group + lane / ppp;
+        // the samples of one pixel sit in neighbouring lanes, so that their accumulator adds can be merged (accum_merged)
+        pix = (pkt % packets_per_group) * ppp + lane / group;
+        s = (uint32_t)(first / fr.n_region_pixels) + (pkt / packets_per_group) * group + lane % group;
     }
     uint32_t xy = slot_xy[pix];
     float x_f = (float)(xy & 0xffffu), y_f = (float)(xy >> 16);
@@ -1042,7 +1067,9 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         const uint32_t shard = ((base - chunk_begin) / RR_BLOCK) % RR_SQ_SHARDS; // the 4 packets of a workgroup iteration stay together
         uint32_t* const sq_count = sq_counts + shard;
         const uint32_t sq_base = shard * sq_segcap;
-        if (!active) continue;
+        long long sum_r = 0, sum_g = 0, sum_b = 0; // this hit's direct adds, merged with its neighbours' at the end
+        uint32_t sum_pix = 0xffffffffu;
+        if (active) {
         n_shaded++;
         const float4 r0 = qin.r0[i], r1 = qin.r1[i];
         const uint2 r2 = qin.r2[i];
@@ -1177,8 +1204,10 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         // ---- constant part: fog colour and ambient / emissive (:977-994)
         {
             float fa = fog_amount * ao;
-            accum_rgb(acc, pix, thr * (fr.fog_color[0] * fa + ambient_color.x), thr * (fr.fog_color[1] * fa + ambient_color.y),
-                      thr * (fr.fog_color[2] * fa + ambient_color.z));
+            sum_pix = pix;
+            sum_r += to_fix(thr * (fr.fog_color[0] * fa + ambient_color.x), RR_FIX_SCALE, RR_FIX_CLAMP);
+            sum_g += to_fix(thr * (fr.fog_color[1] * fa + ambient_color.y), RR_FIX_SCALE, RR_FIX_CLAMP);
+            sum_b += to_fix(thr * (fr.fog_color[2] * fa + ambient_color.z), RR_FIX_SCALE, RR_FIX_CLAMP);
         }
         // ---- object id (:744, :966-969): the last sample's id, passed through fully transparent hits
         const bool child_idc = idc && spawn_refr && approx_equal(alpha, 0.0f);
@@ -1216,7 +1245,9 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
             const float cb = ((L.color[2] * (specular_color.z * light_power + base_color.z * dot_light)) * intensity) * w_light;
             const bool nonzero = (cr != 0.0f) || (cg != 0.0f) || (cb != 0.0f);
             const bool want_shadow = (m.flags & RR_MF_RECEIVE_SHADOW) != 0u && nonzero;
-            if (!(m.flags & RR_MF_RECEIVE_SHADOW) && nonzero) accum_rgb(acc, pix, cr, cg, cb);
+            if (!(m.flags & RR_MF_RECEIVE_SHADOW) && nonzero) {
+                sum_r += to_fix(cr, RR_FIX_SCALE, RR_FIX_CLAMP); sum_g += to_fix(cg, RR_FIX_SCALE, RR_FIX_CLAMP); sum_b += to_fix(cb, RR_FIX_SCALE, RR_FIX_CLAMP);
+            }
             const uint32_t si = sq_base + wave_alloc(sq_count, want_shadow, lane);
             if (want_shadow) {
                 f3 so = hit_point + (surface_normal * 0.001f);
@@ -1262,6 +1293,8 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
                 n_secondary++;
             }
         }
+        } // active
+        accum_merged(acc, sum_pix, sum_r, sum_g, sum_b);
     }
     // per-wave reduction of the work counters
     for (int off = 32; off > 0; off >>= 1) {
@@ -1318,6 +1351,8 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DScen
         if (p >= n_packets) break;
         {
         const uint32_t j = p * RR_WAVE + lane;
+        long long sum_r = 0, sum_g = 0, sum_b = 0;
+        uint32_t sum_pix = 0xffffffffu;
         if (j < n) {
             uint32_t lo = 0, hi = RR_SQ_SHARDS; // largest shard with prefix <= j
             while (hi - lo > 1u) { uint32_t mid = (lo + hi) >> 1; if (s_prefix[mid] <= j) lo = mid; else hi = mid; }
@@ -1346,8 +1381,11 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DScen
                 }
                 factor = 1.0f - shadow_source_alpha;
             }
-            accum_rgb(acc, __float_as_uint(s2.w), s2.x * factor, s2.y * factor, s2.z * factor);
+            sum_pix = __float_as_uint(s2.w);
+            sum_r = to_fix(s2.x * factor, RR_FIX_SCALE, RR_FIX_CLAMP); sum_g = to_fix(s2.y * factor, RR_FIX_SCALE, RR_FIX_CLAMP);
+            sum_b = to_fix(s2.z * factor, RR_FIX_SCALE, RR_FIX_CLAMP);
         }
+        accum_merged(acc, sum_pix, sum_r, sum_g, sum_b);
         }
     }
 }
