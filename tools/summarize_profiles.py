@@ -11,11 +11,11 @@ tag, name = sys.argv[1], sys.argv[2]  # e.g. r01c r01
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(os.path.join(src, "bench_n1.json"), f"profiles/{name}_bench_sponza_syn_n1.json")
-stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)  # gpurun merges into older local copies
 shutil.copy(stats, f"profiles/{name}_kernel_stats_sponza_syn.csv")
 data = {}
 for cname, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    f = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
