@@ -840,7 +840,8 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
                 // shadow sub-queues: a shard gets the packets with (packet % RR_SQ_SHARDS == shard), L rays per hit at most
                 const uint64_t groups = (c1 - c0 + RR_BLOCK - 1) / RR_BLOCK; // 256-ray groups, dealt round-robin to the shards
                 const uint32_t segcap = (uint32_t)(((groups + RR_SQ_SHARDS - 1) / RR_SQ_SHARDS) * RR_BLOCK * std::max(L, 1u));
-                uint32_t* sq_counts = words(RR_SQ_SHARDS);
+                next_word = (next_word + 31u) & ~31u; // the append counters start on a 128-B line
+                uint32_t* sq_counts = words(RR_SQ_SHARDS * RR_SQ_STRIDE);
                 uint32_t* shead = words(1);
                 if (!sq_counts || !shead) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise RR_SHADE_CHUNK");
                 {

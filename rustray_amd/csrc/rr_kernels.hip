@@ -25,6 +25,9 @@
 
 #define RR_BLOCK 256
 #define RR_SQ_SHARDS 32 // sub-queues of the shadow queue, one append counter each
+#ifndef RR_SQ_STRIDE
+#define RR_SQ_STRIDE 32 // words between two append counters: one 128-B line each
+#endif
 #ifndef RR_TRACE_WAVES
 #define RR_TRACE_WAVES 4 // waves per SIMD the trace kernels are built for (bounds VGPRs; LDS stack: RR_STACK_DEPTH KB per workgroup)
 #endif
@@ -1065,7 +1068,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         // (~90 returning atomics per microsecond) that capped this kernel at one 64-ray packet per ~11 ns.
         // Shard capacity is static: a shard receives at most its share of the chunk's packets.
         const uint32_t shard = ((base - chunk_begin) / RR_BLOCK) % RR_SQ_SHARDS; // the 4 packets of a workgroup iteration stay together
-        uint32_t* const sq_count = sq_counts + shard;
+        uint32_t* const sq_count = sq_counts + shard * RR_SQ_STRIDE;
         const uint32_t sq_base = shard * sq_segcap;
         long long sum_r = 0, sum_g = 0, sum_b = 0; // this hit's direct adds, merged with its neighbours' at the end
         uint32_t sum_pix = 0xffffffffu;
@@ -1318,7 +1321,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DScen
     __shared__ uint32_t s_prefix[RR_SQ_SHARDS + 1];
     // dense index space over the shards: prefix sums of their counts
     if (threadIdx.x < RR_WAVE) {
-        uint32_t c = threadIdx.x < RR_SQ_SHARDS ? sq_counts[threadIdx.x] : 0u;
+        uint32_t c = threadIdx.x < RR_SQ_SHARDS ? sq_counts[threadIdx.x * RR_SQ_STRIDE] : 0u;
         uint32_t incl = c;
         for (int off = 1; off < RR_SQ_SHARDS; off <<= 1) { uint32_t v = __shfl_up(incl, off); if ((int)threadIdx.x >= off) incl += v; }
         if (threadIdx.x < RR_SQ_SHARDS) s_prefix[threadIdx.x + 1] = incl;
