@@ -98,7 +98,7 @@ struct rr_scene {
     uint32_t* h_count = nullptr; // pinned: level sizes read back between depth levels
 };
 
-static const uint32_t POOL_WORDS = 1u << 18; // per-batch counters (level sizes, fetch heads, shadow shard counts): 1 MB, zeroed per batch
+static const uint32_t POOL_WORDS = 1u << 22; // per-batch counters (level sizes, fetch heads, shadow shard counts): 16 MB, zeroed per batch
 
 // ---------------------------------------------------------------------------
 // the reference's sub-sample table: StdRng::seed_from_u64(0) + shuffle + truncate

@@ -26,7 +26,7 @@
 #define RR_BLOCK 256
 #define RR_SQ_SHARDS 32 // sub-queues of the shadow queue, one append counter each
 #ifndef RR_SQ_STRIDE
-#define RR_SQ_STRIDE 32 // words between two append counters: one 128-B line each
+#define RR_SQ_STRIDE 16 // words between two append counters: 64 B apart (packed into one line they cost k_shade 13-20 %)
 #endif
 #ifndef RR_TRACE_WAVES
 #define RR_TRACE_WAVES 4 // waves per SIMD the trace kernels are built for (bounds VGPRs; LDS stack: RR_STACK_DEPTH KB per workgroup)
