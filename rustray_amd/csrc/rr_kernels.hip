@@ -1055,9 +1055,15 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
     const uint32_t lane = threadIdx.x & (RR_WAVE - 1);
     const bool gw = sc.general_w != 0u;
     uint32_t n_shaded = 0, n_shadow = 0, n_secondary = 0;
-    const uint32_t wave_global = blockIdx.x * (RR_BLOCK / RR_WAVE) + threadIdx.x / RR_WAVE;
-    const uint32_t wave_stride = gridDim.x * (RR_BLOCK / RR_WAVE) * RR_WAVE;
-    for (uint32_t base = chunk_begin + wave_global * RR_WAVE; base < n; base += wave_stride) {
+    // the four waves of a workgroup walk four neighbouring packets per iteration and allocate their children together
+    // (one atomic per workgroup iteration: a single append counter sustains ~90 returning atomics per microsecond, which
+    // made it THE limiter of this kernel on scenes where most hits spawn children)
+    __shared__ uint32_t s_child_n[2][RR_BLOCK / RR_WAVE];
+    __shared__ uint32_t s_child_base[2];
+    const uint32_t wave_in_block = threadIdx.x / RR_WAVE;
+    uint32_t parity = 0;
+    for (uint32_t block_base = chunk_begin + blockIdx.x * RR_BLOCK; block_base < n; block_base += gridDim.x * RR_BLOCK, parity ^= 1u) {
+        const uint32_t base = block_base + wave_in_block * RR_WAVE;
         const uint32_t i = base + lane;
         uint4 hit = make_uint4(0u, 0xffffffffu, 0u, 0u);
         if (i < n) hit = qin.hit[i];
@@ -1071,6 +1077,10 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         uint32_t* const sq_count = sq_counts + shard * RR_SQ_STRIDE;
         const uint32_t sq_base = shard * sq_segcap;
         long long sum_r = 0, sum_g = 0, sum_b = 0; // this hit's direct adds, merged with its neighbours' at the end
+        // children of this hit (emitted after the hit is shaded, by all waves of the workgroup together)
+        bool spawn_refl = false, spawn_refr = false;
+        float4 c1_r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1_r1 = c1_r0, c2_r0 = c1_r0, c2_r1 = c1_r0;
+        uint2 c1_r2 = make_uint2(0u, 0u), c2_r2 = c1_r2;
         uint32_t sum_pix = 0xffffffffu;
         if (active) {
         n_shaded++;
@@ -1174,8 +1184,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         float reflectivity = m.reflectivity;
         if (tex_color(sc, m, has_uv, uv, 7, &tc)) reflectivity = tc.x;
         const bool may_recurse = depth <= fr.max_recursion;
-        const bool spawn_refl = reflectivity > 0.0f && may_recurse;
-        bool spawn_refr = false;
+        spawn_refl = reflectivity > 0.0f && may_recurse;
         f3 refr_o = mk3(0.0f, 0.0f, 0.0f), refr_d = mk3(0.0f, 0.0f, 0.0f);
         float a_mul = 1.0f; // the factor `color * alpha` applies to what is already in `color`
         if (alpha < 1.0f && may_recurse) {
@@ -1264,40 +1273,50 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
             }
         }
 
-        // ---- children (:938-971), compacted into the next level's queue
+        // ---- children (:938-971): prepared here, compacted into the next level's queue below
         const uint32_t child_meta = sample | ((depth + 1u) << 16);
-        {
-            // one allocation for both kinds of children: reflection rays of the wave first, then refraction rays
-            const unsigned long long m_refl = __ballot(spawn_refl), m_refr = __ballot(spawn_refr);
-            const uint32_t n_refl = (uint32_t)__popcll(m_refl), n_both = n_refl + (uint32_t)__popcll(m_refr);
-            uint32_t obase = 0u;
-            if (n_both) {
-                const int leader = __ffsll((long long)(m_refl | m_refr)) - 1;
-                if ((int)lane == leader) obase = atomicAdd(qout_count, n_both);
-                obase = __shfl(obase, leader);
-            }
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if (spawn_refl) {
-                // create_reflection (:492-498)
-                const uint32_t oi = obase + (uint32_t)__popcll(m_refl & below);
-                f3 o2 = hit_point + (surface_normal * 0.001f);
-                f3 d2 = normalize3(rd - ((2.0f * dot3(rd, surface_normal)) * surface_normal));
-                qout.r0[oi] = make_float4(o2.x, o2.y, o2.z, w_refl);
-                qout.r1[oi] = make_float4(d2.x, d2.y, d2.z, __uint_as_float(pix));
-                qout.r2[oi] = make_uint2(child_meta, node * 2u);
-                n_secondary++;
-            }
-            if (spawn_refr) {
-                const uint32_t oi = obase + n_refl + (uint32_t)__popcll(m_refr & below);
-                f3 d2 = normalize3(refr_d);
-                qout.r0[oi] = make_float4(refr_o.x, refr_o.y, refr_o.z, w_refr);
-                qout.r1[oi] = make_float4(d2.x, d2.y, d2.z, __uint_as_float(pix));
-                qout.r2[oi] = make_uint2(child_meta | (child_idc ? (1u << 24) : 0u), node * 2u + 1u);
-                n_secondary++;
-            }
+        if (spawn_refl) {
+            // create_reflection (:492-498)
+            f3 o2 = hit_point + (surface_normal * 0.001f);
+            f3 d2 = normalize3(rd - ((2.0f * dot3(rd, surface_normal)) * surface_normal));
+            c1_r0 = make_float4(o2.x, o2.y, o2.z, w_refl);
+            c1_r1 = make_float4(d2.x, d2.y, d2.z, __uint_as_float(pix));
+            c1_r2 = make_uint2(child_meta, node * 2u);
+            n_secondary++;
+        }
+        if (spawn_refr) {
+            f3 d2 = normalize3(refr_d);
+            c2_r0 = make_float4(refr_o.x, refr_o.y, refr_o.z, w_refr);
+            c2_r1 = make_float4(d2.x, d2.y, d2.z, __uint_as_float(pix));
+            c2_r2 = make_uint2(child_meta | (child_idc ? (1u << 24) : 0u), node * 2u + 1u);
+            n_secondary++;
         }
         } // active
         accum_merged(acc, sum_pix, sum_r, sum_g, sum_b);
+        {
+            // one allocation for all children of the workgroup iteration: per wave the reflection rays first, then the refraction rays
+            const unsigned long long m_refl = __ballot(spawn_refl), m_refr = __ballot(spawn_refr);
+            const uint32_t n_refl = (uint32_t)__popcll(m_refl), n_both = n_refl + (uint32_t)__popcll(m_refr);
+            if (lane == 0) s_child_n[parity][wave_in_block] = n_both;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t total = 0;
+                for (uint32_t w2 = 0; w2 < RR_BLOCK / RR_WAVE; w2++) total += s_child_n[parity][w2];
+                s_child_base[parity] = total ? atomicAdd(qout_count, total) : 0u;
+            }
+            __syncthreads();
+            uint32_t obase = s_child_base[parity];
+            for (uint32_t w2 = 0; w2 < wave_in_block; w2++) obase += s_child_n[parity][w2];
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (spawn_refl) {
+                const uint32_t oi = obase + (uint32_t)__popcll(m_refl & below);
+                qout.r0[oi] = c1_r0; qout.r1[oi] = c1_r1; qout.r2[oi] = c1_r2;
+            }
+            if (spawn_refr) {
+                const uint32_t oi = obase + n_refl + (uint32_t)__popcll(m_refr & below);
+                qout.r0[oi] = c2_r0; qout.r1[oi] = c2_r1; qout.r2[oi] = c2_r2;
+            }
+        }
     }
     // per-wave reduction of the work counters
     for (int off = 32; off > 0; off >>= 1) {
