@@ -32,9 +32,12 @@
 #define RR_TRACE_WAVES 4 // waves per SIMD the trace kernels are built for (bounds VGPRs; LDS stack: RR_STACK_DEPTH KB per workgroup)
 #endif
 #define RR_WAVE 64
+#ifndef RR_DYN_FETCH
+#define RR_DYN_FETCH 4
+#endif
 #ifndef RR_SHADOW_STATIC_NUM
-#define RR_SHADOW_STATIC_NUM 3
-#define RR_SHADOW_STATIC_DEN 4
+#define RR_SHADOW_STATIC_NUM 1
+#define RR_SHADOW_STATIC_DEN 2
 #endif
 
 __constant__ float c_u8_to_f32[256]; // i / 255.0f, exactly as `(p[0] as f32) / 255.0`
@@ -879,8 +882,8 @@ RR_DEV void accum_merged(const DAccum& acc, uint32_t pix, long long r, long long
 // (One returning atomic on a single word sustains ~90 per microsecond on MI355X: at one per 64 rays that
 // alone caps a kernel at ~5.6 G rays/s and was the limiter of k_shade's queue appends, see DESIGN.md.)
 #ifndef RR_STATIC_NUM
-#define RR_STATIC_NUM 3
-#define RR_STATIC_DEN 4
+#define RR_STATIC_NUM 1
+#define RR_STATIC_DEN 2
 #endif
 #ifndef RR_FETCH
 #define RR_FETCH 2 // measured on sponza_syn: 1 -> 36.2, 2 -> 32.4, 4 -> 42.3 ms in k_trace_closest
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_closest(DSce
     // Work distribution.  Locality decides here: the waves that run side by side must walk neighbouring
     // packets (runs of consecutive packets per wave cost 1.8x, measured), and one head word sustains only ~90
     // fetches per microsecond.  So RR_STATIC_NUM/RR_STATIC_DEN of the packets are dealt round-robin with no atomic
-    // at all, and only the tail is pulled one packet at a time from the shared head to absorb expensive packets.
+    // at all, and the rest is pulled a few packets at a time from the shared head to absorb expensive packets.
     // Blocks b and b + 8 share an XCD (and its L2): with RR_XCD_SWIZZLE the blocks of one XCD take one
     // contiguous run of packets per round instead of every eighth group.
     const uint32_t n_waves = gridDim.x * (RR_BLOCK / RR_WAVE);
@@ -996,14 +999,20 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_closest(DSce
     const uint32_t n_packets = (n + RR_WAVE - 1) / RR_WAVE;
     const uint32_t rounds = (uint32_t)(((unsigned long long)n_packets * RR_STATIC_NUM / RR_STATIC_DEN) / n_waves);
     const uint32_t n_static = rounds * n_waves;
-    uint32_t round = 0;
+    uint32_t round = 0, dyn_next = 0, dyn_left = 0;
+    // packets per fetch of the dynamic part: RR_DYN_FETCH on large launches (more costs locality: +4 % at 8, +10 % at 16), fewer when
+    // the launch has only a few packets per wave
+    const uint32_t dyn_k = n_packets >= 8u * n_waves ? (uint32_t)RR_DYN_FETCH : (n_packets >= 2u * n_waves ? 2u : 1u);
     for (;;) {
         uint32_t pkt;
         if (round < rounds) { pkt = round * n_waves + wave_id; round++; }
         else {
-            uint32_t f = 0;
-            if (lane == 0) f = atomicAdd(head, 1u);
-            pkt = n_static + __shfl(f, 0);
+            if (dyn_left == 0u) { // several packets per atomic: the head word sustains only ~90 fetches per microsecond
+                uint32_t f = 0;
+                if (lane == 0) f = atomicAdd(head, dyn_k);
+                dyn_next = n_static + __shfl(f, 0); dyn_left = dyn_k;
+            }
+            pkt = dyn_next++; dyn_left--;
         }
         if (pkt >= n_packets) break; // wave-uniform
         const uint32_t i = pkt * RR_WAVE + lane;
@@ -1361,14 +1370,20 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DScen
     const uint32_t wave_id = blk * (RR_BLOCK / RR_WAVE) + threadIdx.x / RR_WAVE;
     const uint32_t rounds = (uint32_t)(((unsigned long long)n_packets * RR_SHADOW_STATIC_NUM / RR_SHADOW_STATIC_DEN) / n_waves);
     const uint32_t n_static = rounds * n_waves;
-    uint32_t round = 0;
+    uint32_t round = 0, dyn_next = 0, dyn_left = 0;
+    // packets per fetch of the dynamic part: RR_DYN_FETCH on large launches (more costs locality: +4 % at 8, +10 % at 16), fewer when
+    // the launch has only a few packets per wave
+    const uint32_t dyn_k = n_packets >= 8u * n_waves ? (uint32_t)RR_DYN_FETCH : (n_packets >= 2u * n_waves ? 2u : 1u);
     for (;;) {
         uint32_t p;
         if (round < rounds) { p = round * n_waves + wave_id; round++; }
         else {
-            uint32_t f = 0;
-            if (lane == 0) f = atomicAdd(head, 1u);
-            p = n_static + __shfl(f, 0);
+            if (dyn_left == 0u) {
+                uint32_t f = 0;
+                if (lane == 0) f = atomicAdd(head, dyn_k);
+                dyn_next = n_static + __shfl(f, 0); dyn_left = dyn_k;
+            }
+            p = dyn_next++; dyn_left--;
         }
         if (p >= n_packets) break;
         {
