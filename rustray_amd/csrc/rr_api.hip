@@ -80,7 +80,7 @@ struct rr_scene {
     DevBuf arena[4];  // ray records of all live depth levels, SoA: r0 r1 r2 hit
     size_t arena_cap = 0; // rays
     uint32_t arena_factor = 3; // arena rays per primary ray of a batch; doubled after a frame that had to slice levels
-    DevBuf sq[4];
+    DevBuf sq[3];
     size_t sq_cap = 0;
     DevBuf acc_rgb, acc_normal, acc_depth, acc_id;
     DevBuf region_xy, trace_order, sample_xy, pool, counters; // region_xy: pixel of each accumulator slot; trace_order: its output index
@@ -240,6 +240,7 @@ static int validate_scene(const rr_flat_scene* fs) {
     if ((fs->n_items && !fs->items) || (fs->n_meshes && !fs->meshes) || (fs->n_materials && !fs->materials) ||
         (fs->n_textures && !fs->textures) || (fs->n_lights && !fs->lights))
         return fail(RR_ERR_INVALID_ARGUMENT, "array pointer is NULL with a non-zero count");
+    if (fs->n_items >= (1u << 27)) return fail(RR_ERR_UNSUPPORTED, "%u items (the shadow-ray record keeps the item index in 27 bits)", fs->n_items);
     for (uint32_t i = 0; i < fs->n_textures; i++) {
         const rr_texture& t = fs->textures[i];
         if ((uint64_t)t.width * t.height > 0 && !t.rgba8) return fail(RR_ERR_INVALID_ARGUMENT, "texture %u has no pixels", i);
@@ -574,7 +575,8 @@ extern "C" void rr_scene_destroy(rr_scene* s) {
                      &s->acc_rgb, &s->acc_normal, &s->acc_depth, &s->acc_id, &s->region_xy, &s->trace_order, &s->sample_xy, &s->pool, &s->counters};
     for (DevBuf* b : all) b->release();
     for (int k = 0; k < 4; k++) s->arena[k].release();
-    for (int k = 0; k < 4; k++) { s->sq[k].release(); s->tmp_out[k].release(); }
+    for (int k = 0; k < 4; k++) s->tmp_out[k].release();
+    for (int k = 0; k < 3; k++) s->sq[k].release();
     for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
     for (auto& t : s->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     if (s->frame_a) (void)hipEventDestroy(s->frame_a);
@@ -783,7 +785,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     const uint64_t chunk = env_chunk ? std::max<uint64_t>(65536, (uint64_t)atoll(env_chunk)) : (64ull << 20);
     const uint64_t sq_need = std::max<uint64_t>(1, (std::min<uint64_t>(chunk, M) + RR_BLOCK * RR_SQ_SHARDS) * std::max<uint32_t>(s->n_enabled_lights, 1u));
     if (sq_need > s->sq_cap) {
-        for (int k = 0; k < 4; k++) HIP_TRY(s->sq[k].reserve(sq_need * 16));
+        for (int k = 0; k < 3; k++) HIP_TRY(s->sq[k].reserve(sq_need * 16));
         s->sq_cap = sq_need;
     }
     auto queue_at = [&](uint64_t base) {
@@ -792,7 +794,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         q.r2 = s->arena[2].as<uint2>() + base; q.hit = s->arena[3].as<uint4>() + base;
         return q;
     };
-    DShadowQueue SQ{s->sq[0].as<float4>(), s->sq[1].as<float4>(), s->sq[2].as<float4>(), s->sq[3].as<uint4>()};
+    DShadowQueue SQ{s->sq[0].as<float4>(), s->sq[1].as<float4>(), s->sq[2].as<float4>()};
 
     uint32_t* pool = s->pool.as<uint32_t>();
     unsigned long long* counters = s->counters.as<unsigned long long>();

@@ -145,16 +145,14 @@ struct DRayQueue {
     uint4* hit;
 };
 
-// shadow-ray queue, 64 B per ray
+// shadow-ray queue, 48 B per ray
 //   s0 = (origin.xyz, limit)      limit = distance to the light, or +FLT_MAX for directional lights
-//   s1 = (dir.xyz, receiver material alpha)
+//   s1 = (dir.xyz, bits(receiver item | depth << 27))   the receiver's material alpha is looked up for occluded rays only
 //   s2 = (contribution rgb, bits(accumulator slot))
-//   s3 = (receiver item, depth, 0, 0)
 struct DShadowQueue {
     float4* s0;
     float4* s1;
     float4* s2;
-    uint4* s3;
 };
 
 // fixed-point accumulators: colour and normal scaled by 2^24, depth by 2^16

@@ -1275,9 +1275,8 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
                 f3 sd = to_light;
                 if (mc) sd = jitter(sd, m.shadow_softness, rk, 1u + li);
                 sq.s0[si] = make_float4(so.x, so.y, so.z, limit);
-                sq.s1[si] = make_float4(sd.x, sd.y, sd.z, m.alpha);
+                sq.s1[si] = make_float4(sd.x, sd.y, sd.z, __uint_as_float((uint32_t)item_idx | (depth << 27)));
                 sq.s2[si] = make_float4(cr, cg, cb, __uint_as_float(pix));
-                sq.s3[si] = make_uint4((uint32_t)item_idx, depth, 0u, 0u);
                 n_shadow++;
             }
         }
@@ -1396,18 +1395,18 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DScen
             const uint32_t i = lo * sq_segcap + (j - s_prefix[lo]);
             const float4 s0 = sq.s0[i];
             const float4 s1 = sq.s1[i], s2 = sq.s2[i];
-            const uint4 s3 = sq.s3[i];
+            const uint32_t rcv_item = __float_as_uint(s1.w) & 0x07ffffffu, rcv_depth = __float_as_uint(s1.w) >> 27;
             const f3 o = mk3(s0.x, s0.y, s0.z), d = mk3(s1.x, s1.y, s1.z);
             ShadowSel sel;
-            trace_shadow_ray(sc, o, d, s3.y, s0.w, s_stack, &sel);
+            trace_shadow_ray(sc, o, d, rcv_depth, s0.w, s_stack, &sel);
             const bool occluded = sel.found && sel.within;
             float factor = 1.0f;
             if (occluded) {
-                float shadow_source_alpha = s1.w; // the RECEIVER's material.alpha (:898)
+                float shadow_source_alpha = sc.materials[sc.items[rcv_item].material].alpha; // the RECEIVER's material.alpha (:898)
                 const DItem& occ = sc.items[sel.item];
                 if (occ.flags & RR_IF_OCCLUDER_ALPHA_TEX) {
                     // the reference evaluates the RECEIVER's get_uv with the occluder's face id (:905)
-                    const DItem& rcv = sc.items[s3.x];
+                    const DItem& rcv = sc.items[rcv_item];
                     const f3 shp = o + (d * sel.t);
                     f2 uv;
                     if (rcv.flags & RR_IF_SPHERE) uv = sphere_uv(rcv, shp, gw);
