@@ -71,7 +71,7 @@ struct rr_scene {
     int n_cus = 256;
     std::mutex mu;
     // scene data
-    DevBuf items, nodes, nodes4, tris, trix, attrs, face_slot, materials, textures, texels, lights;
+    DevBuf items, nodes, nodes4, tnodes4, tris, trix, attrs, face_slot, materials, textures, texels, lights;
     DSceneView view{};
     std::vector<DItem> h_items;
     uint32_t n_enabled_lights = 0;
@@ -313,7 +313,8 @@ static void world_box(const rr_item& it, float* lo, float* hi) {
     }
 }
 
-static int build_tlas(rr_scene* s, const std::vector<rr_item>& items, std::vector<DNode>* tlas, int32_t* root) {
+static int build_tlas(rr_scene* s, const std::vector<rr_item>& items, std::vector<DNode>* tlas, int32_t* root,
+                      std::vector<DNode4>* tlas4, int32_t* root4) {
     uint32_t n = (uint32_t)items.size();
     std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
     for (uint32_t i = 0; i < n; i++) world_box(items[i], &lo[3 * (size_t)i], &hi[3 * (size_t)i]);
@@ -330,6 +331,15 @@ static int build_tlas(rr_scene* s, const std::vector<rr_item>& items, std::vecto
     }
     *root = r.root;
     if (r.root < 0) *root = ~(int32_t)r.order[RR_LEAF_FIRST(~r.root)];
+    // the form the kernels walk: collapsed to 4-wide nodes within the top level's share of the traversal stack
+    {
+        rr::BvhResult r4 = r;
+        r4.root = *root;
+        int pending = 0;
+        tlas4->clear();
+        *root4 = rr::collapse_bvh4(r4, RR_TLAS_MAX_DEPTH, tlas4, &pending);
+        if (pending > RR_TLAS_MAX_DEPTH) return fail(RR_ERR_UNSUPPORTED, "top level: BVH4 stack bound exceeded");
+    }
     *tlas = std::move(r.nodes);
     (void)s;
     return RR_OK;
@@ -524,10 +534,11 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     // The reference's choice between "all items" and its scene BVH (src/raytracing.rs:434) only changes the
     // candidate set, never the result.
     std::vector<DNode> tlas;
-    int32_t tlas_root = (int32_t)0x80000000; // RR_SENTINEL: empty scene
+    std::vector<DNode4> tlas4;
+    int32_t tlas_root = (int32_t)0x80000000, tlas_root4 = (int32_t)0x80000000; // RR_SENTINEL: empty scene
     if (fs->n_items >= 1) {
         std::vector<rr_item> items(fs->items, fs->items + fs->n_items);
-        rc = build_tlas(s.get(), items, &tlas, &tlas_root);
+        rc = build_tlas(s.get(), items, &tlas, &tlas_root, &tlas4, &tlas_root4);
         if (rc != RR_OK) return rc;
     }
     uint32_t tlas_base = (uint32_t)all_nodes.size();
@@ -542,6 +553,8 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     };
     HIP_TRY(upload(s->nodes, all_nodes.data(), all_nodes.size() * sizeof(DNode)));
     HIP_TRY(upload(s->nodes4, all_nodes4.data(), all_nodes4.size() * sizeof(DNode4)));
+    tlas4.resize(std::max<size_t>(tlas4.size(), s->tlas_node_capacity)); // room for rebuilds after transform updates
+    HIP_TRY(upload(s->tnodes4, tlas4.data(), tlas4.size() * sizeof(DNode4)));
     HIP_TRY(upload(s->tris, all_tris.data(), all_tris.size() * sizeof(DTri)));
     HIP_TRY(upload(s->trix, all_trix.data(), all_trix.size() * sizeof(DTriX)));
     HIP_TRY(upload(s->attrs, all_attrs.data(), all_attrs.size() * sizeof(DTriAttr)));
@@ -554,7 +567,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     v.materials = s->materials.as<DMaterial>(); v.textures = s->textures.as<DTexture>(); v.texels = s->texels.as<uint32_t>();
     v.lights = s->lights.as<DLight>();
     v.n_items = fs->n_items; v.n_lights = fs->n_lights;
-    v.tlas_node_base = tlas_base; v.tlas_root = tlas_root; v.general_w = general_w ? 1u : 0u;
+    v.tlas_node_base = tlas_base; v.tlas_root = tlas_root; v.tnodes4 = s->tnodes4.as<DNode4>(); v.tlas_root4 = tlas_root4; v.general_w = general_w ? 1u : 0u;
 
     HIP_TRY(s->pool.reserve(POOL_WORDS * 4));
     HIP_TRY(s->counters.reserve(RR_CNT_WORDS * 8));
@@ -605,12 +618,14 @@ extern "C" int rr_scene_update_transforms(rr_scene* s, const float* trans, const
     HIP_TRY(hipMemcpy(s->items.p, s->h_items.data(), n * sizeof(DItem), hipMemcpyHostToDevice));
     s->view.general_w = general_w ? 1u : 0u;
     {
-        std::vector<DNode> tlas; int32_t root = 0;
-        int rc = build_tlas(s, tmp, &tlas, &root);
+        std::vector<DNode> tlas; std::vector<DNode4> tlas4; int32_t root = 0, root4 = 0;
+        int rc = build_tlas(s, tmp, &tlas, &root, &tlas4, &root4);
         if (rc != RR_OK) return rc;
-        if (tlas.size() > s->tlas_node_capacity) return fail(RR_ERR_DEVICE, "top-level rebuild needs %zu nodes, capacity %u", tlas.size(), s->tlas_node_capacity);
+        if (tlas.size() > s->tlas_node_capacity || tlas4.size() > s->tlas_node_capacity)
+            return fail(RR_ERR_DEVICE, "top-level rebuild needs %zu nodes, capacity %u", tlas.size(), s->tlas_node_capacity);
         if (!tlas.empty()) HIP_TRY(hipMemcpy(s->nodes.as<DNode>() + s->view.tlas_node_base, tlas.data(), tlas.size() * sizeof(DNode), hipMemcpyHostToDevice));
-        s->view.tlas_root = root;
+        if (!tlas4.empty()) HIP_TRY(hipMemcpy(s->tnodes4.p, tlas4.data(), tlas4.size() * sizeof(DNode4), hipMemcpyHostToDevice));
+        s->view.tlas_root = root; s->view.tlas_root4 = root4;
     }
     return RR_OK;
 }

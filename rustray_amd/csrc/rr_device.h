@@ -114,6 +114,8 @@ struct DSceneView {
     uint32_t n_lights;
     uint32_t tlas_node_base; // global node index of the TLAS root's array
     int32_t tlas_root;       // node index relative to tlas_node_base, a leaf code (one item), or RR_SENTINEL (empty scene)
+    const DNode4* tnodes4;   // the top level collapsed to BVH4 (the form the kernels walk)
+    int32_t tlas_root4; uint32_t _pad1;
     uint32_t _pad0;
     uint32_t general_w;      // some trans_inv has a w row other than (0,0,0,1)
 };

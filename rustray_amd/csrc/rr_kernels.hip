@@ -187,8 +187,8 @@ __device__ unsigned long long g_util[32];
 #ifndef RR_BVH4
 #define RR_BVH4 1
 #endif
-#ifndef RR_TLAS_WW
-#define RR_TLAS_WW 1
+#ifndef RR_TLAS4
+#define RR_TLAS4 1
 #endif
 // One top-level inner-node step (explicit depth test; an exhausted stack leaves cur = RR_SENTINEL)
 #define RR_TLAS_STEP(bound_expr)                                                                              \
@@ -517,15 +517,26 @@ RR_DEV void trace_closest_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, 
     best->found = false; best->t = RR_FLT_MAX; best->item = -1; best->face = 0u; best->key = 0.0f;
     // top level: world-space boxes over items (stands in for Scene::get_possible_hits_by_ray,
     // reference src/scene.rs:1715-1722; any conservative candidate set gives the same result)
+#if RR_TLAS4
+    // the top level in the 4-wide form of the per-mesh trees, same step (sentinel-terminated stack)
+    const Slab4 ws = make_slab4(make_slab(o, d));
+    int sp = 1;
+    STK(0) = RR_SENTINEL;
+    int cur = sc.tlas_root4;
+    // while-while: every lane walks the top level until it holds a candidate item (or is done), so the per-mesh
+    // walks below run with the lanes of the wave together instead of one straggler at a time
+    for (;;) {
+        while (cur >= 0) { RR_NODE4_STEP(sc.tnodes4, ws, best->t) }
+        if (cur == RR_SENTINEL) break;
+        closest_item(sc, (int)RR_LEAF_FIRST((uint32_t)~cur), o, d, depth, s_stack, sp, best); // one item per top-level leaf
+        sp--; cur = STK(sp);
+    }
+#else
     const SlabRay sr = make_slab(o, d);
     const DNode* nodes = sc.nodes + sc.tlas_node_base;
     int sp = 0;
     int cur = sc.tlas_root;
     if (cur == RR_SENTINEL) return; // empty scene
-    // (at the top level the explicit depth test measured 5-10 % faster than the sentinel form the per-mesh loops use)
-#if RR_TLAS_WW
-    // while-while: every lane walks the top level until it holds a candidate item (or is done), so the per-mesh
-    // walks below run with the lanes of the wave together instead of one straggler at a time
     for (;;) {
         while (cur >= 0) { RR_TLAS_STEP(best->t) }
         if (cur == RR_SENTINEL) break;
@@ -534,30 +545,6 @@ RR_DEV void trace_closest_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, 
         for (uint32_t i = 0; i < count; i++) closest_item(sc, (int)(first + i), o, d, depth, s_stack, sp, best);
         if (sp == 0) break;
         sp--; cur = STK(sp);
-    }
-#else
-    for (;;) {
-        if (cur >= 0) {
-            const DNode nd = nodes[cur];
-            float bound = best->t;
-            float e0, e1;
-            bool h0 = slab2(nd.n0.x, nd.n0.y, nd.n0.z, nd.n0.w, nd.n2.x, nd.n2.y, sr, bound, &e0);
-            bool h1 = slab2(nd.n1.x, nd.n1.y, nd.n1.z, nd.n1.w, nd.n2.z, nd.n2.w, sr, bound, &e1);
-            int c0 = __float_as_int(nd.n3.x), c1 = __float_as_int(nd.n3.y);
-            if (h0 && h1) {
-                bool swap = e1 < e0;
-                STK(sp) = swap ? c0 : c1; sp++;
-                cur = swap ? c1 : c0;
-            } else if (h0) cur = c0;
-            else if (h1) cur = c1;
-            else { if (sp == 0) break; sp--; cur = STK(sp); }
-        } else {
-            uint32_t code = (uint32_t)~cur;
-            uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
-            for (uint32_t i = 0; i < count; i++) closest_item(sc, (int)(first + i), o, d, depth, s_stack, sp, best);
-            if (sp == 0) break;
-            sp--; cur = STK(sp);
-        }
     }
 #endif
 }
@@ -618,76 +605,66 @@ RR_DEV bool shadow_blocker_item(const DSceneView& sc, int idx, f3 o, f3 d, uint3
 }
 
 RR_DEV bool trace_shadow_blockers(const DSceneView& sc, f3 o, f3 d, uint32_t depth, float limit, const ShadowSel& sel, int* s_stack) {
+    const float bound = sel.key * 1.00001f + 1e-6f; // a blocker's box starts before the occluder's key
+#if RR_TLAS4
+    const Slab4 ws = make_slab4(make_slab(o, d));
+    int sp = 1;
+    STK(0) = RR_SENTINEL;
+    int cur = sc.tlas_root4;
+    for (;;) {
+        while (cur >= 0) { RR_NODE4_STEP(sc.tnodes4, ws, bound) }
+        if (cur == RR_SENTINEL) break;
+        if (shadow_blocker_item(sc, (int)RR_LEAF_FIRST((uint32_t)~cur), o, d, depth, limit, sel, s_stack, sp)) return true;
+        sp--; cur = STK(sp);
+    }
+#else
     const SlabRay sr = make_slab(o, d);
     const DNode* nodes = sc.nodes + sc.tlas_node_base;
     int sp = 0;
     int cur = sc.tlas_root;
     for (;;) {
-        if (cur >= 0) {
-            const DNode nd = nodes[cur];
-            const float bound = sel.key * 1.00001f + 1e-6f; // a blocker's box starts before the occluder's key
-            float e0, e1;
-            bool h0 = slab2(nd.n0.x, nd.n0.y, nd.n0.z, nd.n0.w, nd.n2.x, nd.n2.y, sr, bound, &e0);
-            bool h1 = slab2(nd.n1.x, nd.n1.y, nd.n1.z, nd.n1.w, nd.n2.z, nd.n2.w, sr, bound, &e1);
-            int c0 = __float_as_int(nd.n3.x), c1 = __float_as_int(nd.n3.y);
-            if (h0 && h1) { STK(sp) = c1; sp++; cur = c0; }
-            else if (h0) cur = c0;
-            else if (h1) cur = c1;
-            else { if (sp == 0) break; sp--; cur = STK(sp); }
-        } else {
-            uint32_t code = (uint32_t)~cur;
-            uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
-            for (uint32_t i = 0; i < count; i++)
-                if (shadow_blocker_item(sc, (int)(first + i), o, d, depth, limit, sel, s_stack, sp)) return true;
-            if (sp == 0) break;
-            sp--; cur = STK(sp);
-        }
+        while (cur >= 0) { RR_TLAS_STEP(bound) }
+        if (cur == RR_SENTINEL) break;
+        uint32_t code = (uint32_t)~cur;
+        uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
+        for (uint32_t i = 0; i < count; i++)
+            if (shadow_blocker_item(sc, (int)(first + i), o, d, depth, limit, sel, s_stack, sp)) return true;
+        if (sp == 0) break;
+        sp--; cur = STK(sp);
     }
+#endif
     return false;
 }
 
 RR_DEV void trace_shadow_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, float limit, int* s_stack, ShadowSel* sel) {
     sel->found = false; sel->within = false; sel->key = 0.0f; sel->item = -1; sel->t = 0.0f; sel->face = 0u;
+    // an item whose world box starts beyond the light, or beyond the selected item's key, cannot matter
+#define RR_SHADOW_BOUND (sel->found ? fminf(limit, sel->key * 1.00001f + 1e-6f) : limit)
+#if RR_TLAS4
+    const Slab4 ws = make_slab4(make_slab(o, d));
+    int sp = 1;
+    STK(0) = RR_SENTINEL;
+    int cur = sc.tlas_root4;
+    for (;;) {
+        while (cur >= 0) { RR_NODE4_STEP(sc.tnodes4, ws, RR_SHADOW_BOUND) }
+        if (cur == RR_SENTINEL) break;
+        shadow_item(sc, (int)RR_LEAF_FIRST((uint32_t)~cur), o, d, depth, limit, s_stack, sp, sel);
+        sp--; cur = STK(sp);
+    }
+#else
     const SlabRay sr = make_slab(o, d);
     const DNode* nodes = sc.nodes + sc.tlas_node_base;
     int sp = 0;
     int cur = sc.tlas_root;
     if (cur == RR_SENTINEL) return; // empty scene
-#if RR_TLAS_WW
     for (;;) {
-        // an item whose world box starts beyond the light, or beyond the selected item's key, cannot matter
-        while (cur >= 0) { RR_TLAS_STEP(sel->found ? fminf(limit, sel->key * 1.00001f + 1e-6f) : limit) }
+        while (cur >= 0) { RR_TLAS_STEP(RR_SHADOW_BOUND) }
         if (cur == RR_SENTINEL) break;
         uint32_t code = (uint32_t)~cur;
         uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
         for (uint32_t i = 0; i < count; i++) shadow_item(sc, (int)(first + i), o, d, depth, limit, s_stack, sp, sel);
         if (sp == 0) break;
         sp--; cur = STK(sp);
-    }
-#else
-    for (;;) {
-        if (cur >= 0) {
-            const DNode nd = nodes[cur];
-            // an item whose world box starts beyond the light, or beyond the selected item's key, cannot matter
-            float bound = sel->found ? fminf(limit, sel->key * 1.00001f + 1e-6f) : limit;
-            float e0, e1;
-            bool h0 = slab2(nd.n0.x, nd.n0.y, nd.n0.z, nd.n0.w, nd.n2.x, nd.n2.y, sr, bound, &e0);
-            bool h1 = slab2(nd.n1.x, nd.n1.y, nd.n1.z, nd.n1.w, nd.n2.z, nd.n2.w, sr, bound, &e1);
-            int c0 = __float_as_int(nd.n3.x), c1 = __float_as_int(nd.n3.y);
-            if (h0 && h1) {
-                bool swap = e1 < e0;
-                STK(sp) = swap ? c0 : c1; sp++;
-                cur = swap ? c1 : c0;
-            } else if (h0) cur = c0;
-            else if (h1) cur = c1;
-            else { if (sp == 0) break; sp--; cur = STK(sp); }
-        } else {
-            uint32_t code = (uint32_t)~cur;
-            uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
-            for (uint32_t i = 0; i < count; i++) shadow_item(sc, (int)(first + i), o, d, depth, limit, s_stack, sp, sel);
-            if (sp == 0) break;
-            sp--; cur = STK(sp);
-        }
     }
 #endif
     // The occluder found has a hit within the light distance.  Only if its sort key lies beyond the light (its box
