@@ -16,10 +16,9 @@
 // per-pixel fixed-point accumulators: integer adds commute, hence the frame is
 // bit-identical for any scheduling, batching, tiling or GPU count.
 //
-// Kernels are persistent: a fixed grid of 256-thread workgroups pulls 64-ray
-// packets from the queue with one atomic per wave, so a launch never depends on
-// the (device-resident) queue length and the host never synchronises inside a
-// batch.
+// The trace kernels are persistent: a fixed grid of 256-thread workgroups walks
+// the queue in 64-ray packets, half of them dealt round-robin, half pulled from a
+// shared head; the queue length is read on the device.
 #include "rr_device.h"
 #include "rr_math.h"
 
@@ -855,26 +854,11 @@ RR_DEV void accum_merged(const DAccum& acc, uint32_t pix, long long r, long long
     }
 }
 
-// Persistent packet fetch: one atomic per wave hands out RR_FETCH packets of 64 consecutive queue slots.
-// (One returning atomic on a single word sustains ~90 per microsecond on MI355X: at one per 64 rays that
-// alone caps a kernel at ~5.6 G rays/s and was the limiter of k_shade's queue appends, see DESIGN.md.)
+// Share of a launch's packets that is dealt to the waves round-robin, without an atomic (see k_trace_closest).
 #ifndef RR_STATIC_NUM
 #define RR_STATIC_NUM 1
 #define RR_STATIC_DEN 2
 #endif
-#ifndef RR_FETCH
-#define RR_FETCH 2 // measured on sponza_syn: 1 -> 36.2, 2 -> 32.4, 4 -> 42.3 ms in k_trace_closest
-#endif
-RR_DEV uint32_t wave_fetch(uint32_t* head, uint32_t lane, uint32_t packets) {
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(head, (uint32_t)RR_WAVE * packets);
-    return __shfl(base, 0) + lane;
-}
-// RR_FETCH packets per fetch once every wave of the grid can get that many, else one (short launches of the
-// deep levels would otherwise leave half of the waves idle while the others walk two packets in a row)
-RR_DEV uint32_t fetch_packets(uint32_t n) {
-    return (n >= gridDim.x * (RR_BLOCK / RR_WAVE) * RR_WAVE * RR_FETCH) ? (uint32_t)RR_FETCH : 1u;
-}
 
 // ---------------------------------------------------------------------------
 // kernel 1: primary rays (reference src/raytracing.rs:319-396)
