@@ -285,9 +285,33 @@ RR_DEV Slab4 make_slab4(const SlabRay& r) {
         if (k0 < inf_) cur = c0;                                                                               \
         else { sp--; cur = STK(sp); }                                                                          \
     }
+// The same step for walks that only ask whether anything is hit (shadow queries inside one mesh): the order in which
+// the children are visited does not matter, so the hit children are pushed in slot order and the sort is skipped.
+#define RR_NODE4_STEP_ANY(nodes4, s4, bound)                                                                   \
+    {                                                                                                          \
+        RR_UTIL(2) const float4* np_ = (const float4*)((nodes4) + cur);                                        \
+        const float4 rnx = np_[(s4).sx], rfx = np_[1u - (s4).sx], rny = np_[2u + (s4).sy], rfy = np_[3u - (s4).sy];             \
+        const float4 rnz = np_[4u + (s4).sz], rfz = np_[5u - (s4).sz], cc = np_[6];                           \
+        const float bound_ = (bound);                                                                          \
+        const float inf_ = __builtin_inff();                                                                   \
+        RR_ROW(rnx, (s4).o.x, (s4).inv.x, nx01, nx23) RR_ROW(rfx, (s4).o.x, (s4).inv.x, fx01, fx23)            \
+        RR_ROW(rny, (s4).o.y, (s4).inv.y, ny01, ny23) RR_ROW(rfy, (s4).o.y, (s4).inv.y, fy01, fy23)            \
+        RR_ROW(rnz, (s4).o.z, (s4).inv.z, nz01, nz23) RR_ROW(rfz, (s4).o.z, (s4).inv.z, fz01, fz23)            \
+        RR_CHILD(k0, h0, nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x)                                       \
+        RR_CHILD(k1, h1, nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y)                                       \
+        RR_CHILD(k2, h2, nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x)                                       \
+        RR_CHILD(k3, h3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y)                                       \
+        (void)k0; (void)k1; (void)k2; (void)k3;                                                                \
+        STK(sp) = __float_as_int(cc.w); sp += h3 ? 1 : 0;                                                      \
+        STK(sp) = __float_as_int(cc.z); sp += h2 ? 1 : 0;                                                      \
+        STK(sp) = __float_as_int(cc.y); sp += h1 ? 1 : 0;                                                      \
+        if (h0) cur = __float_as_int(cc.x);                                                                    \
+        else { sp--; cur = STK(sp); }                                                                          \
+    }
 #define RR_BLAS_NODES(sc, it) ((sc).nodes4 + (it).node_base4)
 #define RR_BLAS_ROOT(it) ((it).root4)
 #define RR_BLAS_STEP(nodes, sr, bound) RR_NODE4_STEP(nodes, sr, bound)
+#define RR_BLAS_STEP_ANY(nodes, sr, bound) RR_NODE4_STEP_ANY(nodes, sr, bound)
 #define RR_BLAS_SLAB(r) make_slab4(make_slab((r).o, (r).d))
 typedef DNode4 BlasNode;
 typedef Slab4 BlasSlab;
@@ -295,6 +319,7 @@ typedef Slab4 BlasSlab;
 #define RR_BLAS_NODES(sc, it) ((sc).nodes + (it).node_base)
 #define RR_BLAS_ROOT(it) ((it).root)
 #define RR_BLAS_STEP(nodes, sr, bound) RR_NODE_STEP(nodes, sr, bound)
+#define RR_BLAS_STEP_ANY(nodes, sr, bound) RR_NODE_STEP(nodes, sr, bound)
 #define RR_BLAS_SLAB(r) make_slab((r).o, (r).d)
 typedef DNode BlasNode;
 typedef SlabRay BlasSlab;
@@ -408,7 +433,7 @@ RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, flo
     int pend = 0;
     for (;;) {
         if (cur >= 0) {
-            RR_BLAS_STEP(nodes, sr, any ? limit : RR_FLT_MAX)
+            RR_BLAS_STEP_ANY(nodes, sr, any ? limit : RR_FLT_MAX)
         } else if (pend == 0 && cur != RR_SENTINEL) {
             pend = cur; sp--; cur = STK(sp);
         }
@@ -427,7 +452,7 @@ RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, flo
 #else
     while (cur != RR_SENTINEL) {
         if (cur >= 0) {
-            RR_BLAS_STEP(nodes, sr, any ? limit : RR_FLT_MAX)
+            RR_BLAS_STEP_ANY(nodes, sr, any ? limit : RR_FLT_MAX)
         } else {
             RR_LEAF_ANY(cur)
             if (within) break;
