@@ -1,0 +1,366 @@
+// rustray_host.hpp — C++17 host layer over the C ABI of rustray_hip.h.
+//
+// The reference's host code around the trace loop is compiled Rust; no Rust toolchain exists in this pipeline, so
+// this header restates, in C++, the part of that host code which drives the path: `Camera` (reference
+// src/camera.rs:18-140), `RaytracingConfig` / `PixelData` / `Raytracing` (src/raytracing.rs:57-273) and
+// `RendererManager` (src/renderer.rs:38-251) with the same names, argument meaning and call surface.  What changes
+// behind that surface: `RendererManager::start` does not spawn num_cpus-2 workers over a queue of 2x2-pixel cells
+// (src/renderer.rs:105-172) but ONE thread that issues a frame-level call into librustray_hip.so
+// (rr_render_progressive); finished pixels arrive per pass (every pixel, more samples) instead of cell by cell.
+//
+// Header-only; link against librustray_hip.so.  Nothing here touches the GPU directly.
+#pragma once
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "rustray_hip.h"
+
+namespace rustray {
+
+// helper::approx_equal (reference src/helper.rs:11-20): six truncated decimals, in f32
+inline bool approx_equal(float a, float b) {
+    const float f = 1000000.0f;
+    return std::trunc(a * f) == std::trunc(b * f);
+}
+
+struct Vec3 {
+    float x = 0.0f, y = 0.0f, z = 0.0f;
+};
+
+// reference src/raytracing.rs:57-72
+struct PixelData {
+    uint8_t r = 0, g = 0, b = 0;
+    Vec3 normal;
+    float depth = 0.0f;
+    uint32_t object_id = 0;
+    int32_t x = 0, y = 0;
+};
+
+// reference src/raytracing.rs:92-185
+struct RaytracingConfig {
+    bool monte_carlo = false;
+    uint16_t samples = 1; // this includes anti aliasing
+    float focal_length = 1.0f;
+    float aperture_size = 1.0f; // 1 means off
+    float fog_density = 0.0f;
+    Vec3 fog_color{0.4f, 0.4f, 0.4f};
+    uint16_t max_recursion = 6;
+    bool gamma_correction = false;
+    uint64_t seed = 0; // not in the reference: its jitter draws from an un-seeded thread_rng
+
+    // RaytracingConfig::apply: only fields that differ from the defaults are taken over (src/raytracing.rs:129-185)
+    void apply(const RaytracingConfig& n) {
+        const RaytracingConfig d;
+        if (d.monte_carlo != n.monte_carlo) monte_carlo = n.monte_carlo;
+        if (d.samples != n.samples) samples = n.samples;
+        if (!approx_equal(d.focal_length, n.focal_length)) focal_length = n.focal_length;
+        if (!approx_equal(d.aperture_size, n.aperture_size)) aperture_size = n.aperture_size;
+        if (!approx_equal(d.fog_density, n.fog_density)) fog_density = n.fog_density;
+        if (!approx_equal(d.fog_color.x, n.fog_color.x) || !approx_equal(d.fog_color.y, n.fog_color.y) || !approx_equal(d.fog_color.z, n.fog_color.z))
+            fog_color = n.fog_color;
+        if (d.max_recursion != n.max_recursion) max_recursion = n.max_recursion;
+        if (d.gamma_correction != n.gamma_correction) gamma_correction = n.gamma_correction;
+    }
+
+    rr_config c_struct() const {
+        rr_config c;
+        std::memset(&c, 0, sizeof c);
+        c.seed = seed;
+        c.focal_length = focal_length; c.aperture_size = aperture_size; c.fog_density = fog_density;
+        c.fog_color[0] = fog_color.x; c.fog_color[1] = fog_color.y; c.fog_color[2] = fog_color.z;
+        c.samples = samples; c.max_recursion = max_recursion;
+        c.monte_carlo = monte_carlo ? 1 : 0; c.gamma_correction = gamma_correction ? 1 : 0;
+        return c;
+    }
+};
+
+// reference src/camera.rs:10-15
+constexpr float DEFAULT_FOV = 90.0f;
+constexpr float DEFAULT_CLIPPING_NEAR = 0.001f;
+constexpr float DEFAULT_CLIPPING_FAR = 1000.0f;
+
+// reference src/camera.rs:18-140.  The trace loop consumes width, height and the two inverse matrices only
+// (src/raytracing.rs:282-283, :349, :355, :369-393).  Matrices are column-major like nalgebra's; they are evaluated in
+// double and rounded to f32 once, exactly as rustray_amd/camera.py does, so both host mirrors hand the library the
+// same bits (the camera is harness code, outside the parity contract of the trace loop).
+class Camera {
+public:
+    uint32_t width = 0, height = 0;
+    float aspect_ratio = 0.0f;
+    float fov = (float)(90.0 * 3.14159265358979323846 / 180.0);
+    Vec3 eye_pos{0.0f, 0.0f, 0.0f}, up{0.0f, 1.0f, 0.0f}, dir{0.0f, 0.0f, -1.0f};
+    float clipping_near = DEFAULT_CLIPPING_NEAR, clipping_far = DEFAULT_CLIPPING_FAR;
+    double projection[16], view[16], projection_inverse[16], view_inverse[16]; // column-major
+
+    Camera() {
+        fov = (float)((double)DEFAULT_FOV * 3.14159265358979323846 / 180.0);
+        identity(projection); identity(view); identity(projection_inverse); identity(view_inverse);
+    }
+
+    void init(uint32_t w, uint32_t h) { // src/camera.rs:69-77
+        width = w; height = h;
+        aspect_ratio = (float)w / (float)h;
+        init_matrices();
+    }
+
+    void init_matrices() { // src/camera.rs:79-90: Perspective3::new, Isometry3::look_at_rh and their inverses
+        const double a = aspect_ratio, fovy = fov, zn = clipping_near, zf = clipping_far;
+        const double t = std::tan(fovy / 2.0);
+        zero(projection);
+        at(projection, 0, 0) = 1.0 / (a * t);
+        at(projection, 1, 1) = 1.0 / t;
+        at(projection, 2, 2) = (zf + zn) / (zn - zf);
+        at(projection, 2, 3) = 2.0 * zf * zn / (zn - zf);
+        at(projection, 3, 2) = -1.0;
+        zero(projection_inverse);
+        at(projection_inverse, 0, 0) = 1.0 / at(projection, 0, 0);
+        at(projection_inverse, 1, 1) = 1.0 / at(projection, 1, 1);
+        at(projection_inverse, 2, 3) = -1.0;
+        at(projection_inverse, 3, 2) = 1.0 / at(projection, 2, 3);
+        at(projection_inverse, 3, 3) = at(projection, 2, 2) / at(projection, 2, 3);
+        const double e[3] = {eye_pos.x, eye_pos.y, eye_pos.z};
+        const double tg[3] = {e[0] + (double)dir.x, e[1] + (double)dir.y, e[2] + (double)dir.z};
+        double z[3] = {e[0] - tg[0], e[1] - tg[1], e[2] - tg[2]};
+        normalize(z);
+        const double u[3] = {up.x, up.y, up.z};
+        double x[3]; cross(u, z, x); normalize(x);
+        double y[3]; cross(z, x, y);
+        identity(view);
+        for (int k = 0; k < 3; k++) { at(view, 0, k) = x[k]; at(view, 1, k) = y[k]; at(view, 2, k) = z[k]; }
+        at(view, 0, 3) = -dot(x, e); at(view, 1, 3) = -dot(y, e); at(view, 2, 3) = -dot(z, e);
+        identity(view_inverse);
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) at(view_inverse, r, c) = at(view, c, r);
+        for (int r = 0; r < 3; r++) at(view_inverse, r, 3) = e[r];
+    }
+
+    bool is_default_cam() const { // src/camera.rs:92-123
+        return approx_equal(eye_pos.x, 0.0f) && approx_equal(eye_pos.y, 0.0f) && approx_equal(eye_pos.z, 0.0f) &&
+               approx_equal(dir.x, 0.0f) && approx_equal(dir.y, 0.0f) && approx_equal(dir.z, -1.0f) &&
+               approx_equal(up.x, 0.0f) && approx_equal(up.y, 1.0f) && approx_equal(up.z, 0.0f) &&
+               approx_equal(fov, (float)((double)DEFAULT_FOV * 3.14159265358979323846 / 180.0)) &&
+               approx_equal(clipping_near, DEFAULT_CLIPPING_NEAR) && approx_equal(clipping_far, DEFAULT_CLIPPING_FAR);
+    }
+
+    void set_cam_position(Vec3 eye, Vec3 d) { eye_pos = eye; dir = d; init_matrices(); } // src/camera.rs:125-131
+
+    bool is_point_in_frustum(Vec3 p) const { // src/camera.rs:133-140
+        double pv[16];
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += cat(projection, r, k) * cat(view, k, c);
+            pv[c * 4 + r] = s;
+        }
+        const double h[4] = {p.x, p.y, p.z, 1.0};
+        double o[4];
+        for (int r = 0; r < 4; r++) { o[r] = 0.0; for (int k = 0; k < 4; k++) o[r] += pv[k * 4 + r] * h[k]; }
+        return std::fabs(o[0]) <= o[3] && std::fabs(o[1]) <= o[3] && std::fabs(o[2]) <= o[3];
+    }
+
+    rr_camera c_struct() const {
+        rr_camera c;
+        c.width = width; c.height = height;
+        for (int i = 0; i < 16; i++) { c.projection_inverse[i] = (float)projection_inverse[i]; c.view_inverse[i] = (float)view_inverse[i]; }
+        return c;
+    }
+
+private:
+    static double& at(double* m, int r, int c) { return m[c * 4 + r]; }
+    static double cat(const double* m, int r, int c) { return m[c * 4 + r]; }
+    static void zero(double* m) { for (int i = 0; i < 16; i++) m[i] = 0.0; }
+    static void identity(double* m) { zero(m); m[0] = m[5] = m[10] = m[15] = 1.0; }
+    static double dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+    static void cross(const double* a, const double* b, double* o) {
+        o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+    }
+    static void normalize(double* v) { const double n = std::sqrt(dot(v, v)); v[0] /= n; v[1] /= n; v[2] /= n; }
+};
+
+// A scene resident on one GPU (rr_scene), owned.
+class DeviceScene {
+public:
+    DeviceScene(const rr_flat_scene& flat, int device = 0) {
+        if (rr_scene_create(&flat, device, &h_) != RR_OK) { error_ = rr_last_error(); h_ = nullptr; }
+    }
+    ~DeviceScene() { if (h_) rr_scene_destroy(h_); }
+    DeviceScene(const DeviceScene&) = delete;
+    DeviceScene& operator=(const DeviceScene&) = delete;
+    rr_scene* handle() const { return h_; }
+    bool ok() const { return h_ != nullptr; }
+    const std::string& error() const { return error_; }
+
+private:
+    rr_scene* h_ = nullptr;
+    std::string error_;
+};
+
+// reference src/raytracing.rs:205-273: scene + config; the per-pixel `render(x, y)` is replaced by whole frames
+class Raytracing {
+public:
+    std::shared_ptr<DeviceScene> scene;
+    Camera camera; // Scene::cam in the reference (src/scene.rs:69-83)
+    RaytracingConfig config;
+
+    explicit Raytracing(std::shared_ptr<DeviceScene> s) : scene(std::move(s)) {}
+
+    float gamma_encode(float linear) const { return std::pow(linear, 1.0f / 2.2f); } // src/raytracing.rs:231-235
+
+    // Raytracing::pick (src/raytracing.rs:237-273): Some((id, distance)) of the item under the pixel, or None
+    std::optional<std::pair<uint32_t, float>> pick(int x, int y) const {
+        rr_pick_result r;
+        const rr_camera c = camera.c_struct();
+        if (rr_pick(scene->handle(), &c, x, y, &r) != RR_OK || !r.hit) return std::nullopt;
+        return std::make_pair(r.object_id, r.distance);
+    }
+};
+
+// reference src/renderer.rs:38-251
+class RendererManager {
+public:
+    uint32_t thread_amount = 1; // one frame-level device call replaces the num_cpus - 2 workers (src/renderer.rs:67-71)
+    uint32_t min_passes = 8;    // previews per frame (rr_render_progressive)
+
+    RendererManager(int32_t width, int32_t height, std::shared_ptr<Raytracing> raytracing)
+        : width_(width), height_(height), raytracing_(std::move(raytracing)) {}
+    ~RendererManager() { stop(); join(); }
+
+    void update_resolution(int32_t width, int32_t height) { width_ = width; height_ = height; } // :99-103
+
+    // :105-172.  Returns at once; the frame renders on a worker thread.
+    void start() {
+        join();
+        start_time_ = std::chrono::steady_clock::now();
+        done_ms_ = 0;
+        pixels_rendered_ = 0;
+        cancel_ = 0;
+        failed_ = false;
+        running_ = true;
+        const size_t n = (size_t)width_ * (size_t)height_;
+        {
+            std::lock_guard<std::mutex> lk(frame_mu_);
+            image_.assign(n * 4, 0); normals_.assign(n * 3, 0.0f); depth_.assign(n, 0.0f); objects_.assign(n, 0u);
+            fresh_ = false;
+        }
+        back_rgba_.assign(n * 4, 0); back_normal_.assign(n * 3, 0.0f); back_depth_.assign(n, 0.0f); back_ids_.assign(n, 0u);
+        raytracing_->camera.init((uint32_t)width_, (uint32_t)height_);
+        thread_ = std::thread([this]() { this->run(); });
+    }
+
+    // :174-198: ends the frame early; the buffers keep the last finished pass
+    void stop() {
+        if (!running_.exchange(false)) return;
+        cancel_ = 1;
+        join();
+    }
+
+    void restart(int32_t width, int32_t height) { stop(); update_resolution(width, height); start(); } // :201-208
+
+    bool has_cells_left() const { return running_ && !is_done(); }                     // :210-213
+    uint64_t get_rendered_pixels() const { return pixels_rendered_; }                  // :215-218
+    bool is_running() const { return running_; }                                      // :220-226
+    bool is_done() const { return pixels_rendered_ == (uint64_t)width_ * (uint64_t)height_; } // :228-231
+
+    uint64_t check_and_get_elapsed_time() { // :233-246
+        if (done_ms_ > 0) return done_ms_;
+        const uint64_t ms = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - start_time_).count();
+        if (is_done()) done_ms_ = ms;
+        return ms;
+    }
+
+    // Stands in for get_message_receiver (:248-251) + Run::apply_pixels (src/run.rs:506-545): calls `f` for every pixel
+    // of the newest finished pass, once per pass.  Returns the number of pixels delivered.
+    size_t drain(const std::function<void(const PixelData&)>& f) {
+        std::lock_guard<std::mutex> lk(frame_mu_);
+        if (!fresh_) return 0;
+        fresh_ = false;
+        const size_t n = (size_t)width_ * (size_t)height_;
+        for (size_t i = 0; i < n; i++) {
+            PixelData p;
+            p.r = image_[4 * i]; p.g = image_[4 * i + 1]; p.b = image_[4 * i + 2];
+            p.normal = Vec3{normals_[3 * i], normals_[3 * i + 1], normals_[3 * i + 2]};
+            p.depth = depth_[i]; p.object_id = objects_[i];
+            p.x = (int32_t)(i % (size_t)width_); p.y = (int32_t)(i / (size_t)width_);
+            f(p);
+        }
+        return n;
+    }
+
+    // the four buffers Run::apply_pixels fills (src/run.rs:519-541); copies, safe while a frame renders
+    void frame(std::vector<uint8_t>* rgba, std::vector<float>* normal = nullptr, std::vector<float>* depth = nullptr,
+               std::vector<uint32_t>* object_id = nullptr) {
+        std::lock_guard<std::mutex> lk(frame_mu_);
+        if (rgba) *rgba = image_;
+        if (normal) *normal = normals_;
+        if (depth) *depth = depth_;
+        if (object_id) *object_id = objects_;
+    }
+
+    void wait() { join(); } // not in the reference: block until the frame is done or stopped
+    bool failed() const { return failed_; }
+    std::string last_error() { std::lock_guard<std::mutex> lk(frame_mu_); return error_; }
+    uint32_t passes() const { return passes_; }
+
+private:
+    void join() { if (thread_.joinable()) thread_.join(); }
+
+    static int on_pass(void* user, uint64_t done, uint64_t total) {
+        RendererManager* m = (RendererManager*)user;
+        m->publish();
+        // the reference counts finished pixels; a pass finishes a share of every pixel's samples
+        m->pixels_rendered_ = (uint64_t)m->width_ * (uint64_t)m->height_ * done / total;
+        m->passes_++;
+        return m->running_ ? 0 : 1;
+    }
+
+    void publish() {
+        std::lock_guard<std::mutex> lk(frame_mu_);
+        image_ = back_rgba_; normals_ = back_normal_; depth_ = back_depth_; objects_ = back_ids_;
+        fresh_ = true;
+    }
+
+    void run() {
+        passes_ = 0;
+        const rr_camera cam = raytracing_->camera.c_struct();
+        const rr_config cfg = raytracing_->config.c_struct();
+        rr_frame out{back_rgba_.data(), back_normal_.data(), back_depth_.data(), back_ids_.data()};
+        const int rc = rr_render_progressive(raytracing_->scene->handle(), &cam, &cfg, nullptr, &out, min_passes, &RendererManager::on_pass, this, &cancel_);
+        if (rc == RR_OK) {
+            publish();
+            pixels_rendered_ = (uint64_t)width_ * (uint64_t)height_;
+        } else if (rc != RR_ERR_CANCELLED) {
+            std::lock_guard<std::mutex> lk(frame_mu_);
+            error_ = rr_last_error();
+            failed_ = true;
+        }
+        running_ = false;
+    }
+
+    int32_t width_, height_;
+    std::shared_ptr<Raytracing> raytracing_;
+    std::thread thread_;
+    std::atomic<bool> running_{false}, failed_{false};
+    std::atomic<uint64_t> pixels_rendered_{0};
+    std::atomic<uint32_t> passes_{0};
+    volatile int cancel_ = 0;
+    std::chrono::steady_clock::time_point start_time_ = std::chrono::steady_clock::now();
+    uint64_t done_ms_ = 0;
+    std::mutex frame_mu_;
+    std::vector<uint8_t> image_, back_rgba_;
+    std::vector<float> normals_, depth_, back_normal_, back_depth_;
+    std::vector<uint32_t> objects_, back_ids_;
+    bool fresh_ = false;
+    std::string error_;
+};
+
+} // namespace rustray

@@ -49,7 +49,10 @@ class Camera:
 
     def init_matrices(self) -> None:
         # src/camera.rs:79-90: Perspective3::new + Isometry3::look_at_rh and their inverses
-        a, fovy, zn, zf = self.aspect_ratio, self.fov, self.clipping_near, self.clipping_far
+        # the reference's fields are f32 (src/camera.rs:18-41): round what the caller gave before using it; the matrices
+        # themselves are evaluated in double and rounded once in c_struct() (include/rustray_host.hpp does the same)
+        f32 = lambda v: float(np.float32(v))  # noqa: E731
+        a, fovy, zn, zf = f32(self.aspect_ratio), f32(self.fov), f32(self.clipping_near), f32(self.clipping_far)
         t = math.tan(fovy / 2.0)
         p = np.zeros((4, 4))
         p[0, 0] = 1.0 / (a * t)
@@ -65,11 +68,11 @@ class Camera:
         pi[3, 2] = 1.0 / p[2, 3]
         pi[3, 3] = p[2, 2] / p[2, 3]
         self.projection_inverse = pi
-        eye = np.asarray(self.eye_pos, dtype=np.float64)
-        target = eye + np.asarray(self.dir, dtype=np.float64)
+        eye = np.asarray(self.eye_pos, dtype=np.float32).astype(np.float64)
+        target = eye + np.asarray(self.dir, dtype=np.float32).astype(np.float64)
         z = eye - target
         z = z / np.linalg.norm(z)
-        x = np.cross(np.asarray(self.up, dtype=np.float64), z)
+        x = np.cross(np.asarray(self.up, dtype=np.float32).astype(np.float64), z)
         x = x / np.linalg.norm(x)
         y = np.cross(z, x)
         v = np.eye(4)
