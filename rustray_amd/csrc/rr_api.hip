@@ -790,7 +790,11 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         B = ((total_units + nb - 1) / nb) * unit;
     }
     B = std::min<uint64_t>(B, total_primary);
-    const uint64_t M = std::min<uint64_t>(std::min<uint64_t>((uint64_t)s->arena_factor * B, std::max<uint64_t>(3 * B, budget / 56ull)) + 2ull * RR_BLOCK * (R + 1), LEVEL_MAX);
+    // arena: 3 rays per primary ray, or 8 where that stays under 16 GB (a branching scene then fits on its first frame
+    // too), or `arena_factor` after a frame that had to slice -- always within the budget
+    const uint64_t roomy = std::min<uint64_t>(8 * B, (16ull << 30) / 56ull);
+    const uint64_t want = std::max<uint64_t>(std::max<uint64_t>(3 * B, roomy), (uint64_t)s->arena_factor * B);
+    const uint64_t M = std::min<uint64_t>(std::min<uint64_t>(want, std::max<uint64_t>(3 * B, budget / 56ull)) + 2ull * RR_BLOCK * (R + 1), LEVEL_MAX);
     const size_t elem[4] = {16, 16, 8, 16};
     if (M > s->arena_cap) {
         for (int k = 0; k < 4; k++) HIP_TRY(s->arena[k].reserve(M * elem[k]));
