@@ -14,6 +14,7 @@ from rustray_amd.renderer import TiledFrame, render_region_torch
 args = argparse.Namespace(scene="sponza_syn", width=1280, height=720, spp=128, monte_carlo=1)
 fs, cam, cfg = bench.build_workload(args)
 ds = capi.DeviceScene(fs, 0)
+ds.set_profiling(True)
 camc = cam.c_struct()
 base = None
 for n in (1, 2, 4, 8):
@@ -27,6 +28,9 @@ for n in (1, 2, 4, 8):
         render_region_torch(ds, camc, cfg, tf, aux=False)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 200.0
+    st = ds.stats()
     base = base or ms
-    print(f"N={n}: rank-0 share {ms:7.2f} ms   ideal {base / n:7.2f} ms   efficiency bound {base / n / ms:5.2f}")
+    print(f"N={n}: rank-0 share {ms:7.2f} ms   ideal {base / n:7.2f} ms   efficiency bound {base / n / ms:5.2f}   "
+          f"last frame: device {st['ms_total']:.2f} closest {st['ms_trace_closest']:.2f} shadow {st['ms_trace_shadow']:.2f} shade {st['ms_shade']:.2f} "
+          f"launches {st['launches_trace_closest']}/{st['launches_trace_shadow']}/{st['launches_shade']}")
 ds.close()
