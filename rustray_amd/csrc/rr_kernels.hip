@@ -705,7 +705,10 @@ RR_DEV float4 texel(const DSceneView& sc, const DTexture& t, uint32_t x, uint32_
 }
 RR_DEV uint32_t tex_wrap(float val, uint32_t bound) {
     int32_t sb = (int32_t)bound;
-    int32_t w = as_i32(val * (float)bound) % sb;
+    const int32_t x = as_i32(val * (float)bound);
+    // power-of-two sizes: the mask IS the remainder made non-negative (x % sb, plus sb when negative), without the integer division
+    if ((bound & (bound - 1u)) == 0u) return (uint32_t)x & (bound - 1u);
+    int32_t w = x % sb;
     return (w < 0) ? (uint32_t)(w + sb) : (uint32_t)w;
 }
 RR_DEV float lerp1(float a, float b, float f) { return a + f * (b - a); } // helper::interpolate
@@ -1097,6 +1100,8 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
 
         // ---- world normal: Shape::intersect (mesh.rs:76-98, sphere.rs:61-65)
         f3 normal;
+        DTriAttr at; float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f; bool have_weights = false;
+        at.s0 = at.s1 = at.s2 = at.s3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (it_flags & RR_IF_SPHERE) {
             LRay lr = inverse_ray(it, ro, rd, gw);
             float t2 = 0.0f; bool inside = false;
@@ -1106,11 +1111,15 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         } else {
             const DTri tr = sc.tris[it_tri_base + slot];
             const f3 a = mk3(tr.v0.x, tr.v0.y, tr.v0.z), b = mk3(tr.v1.x, tr.v1.y, tr.v1.z), c = mk3(tr.v2.x, tr.v2.y, tr.v2.z);
-            if (it_flags & RR_IF_SMOOTH) {
-                const DTriAttr at = sc.attrs[it_tri_base + slot];
-                f3 p = to_local_point(it, hit_point, gw);
-                float a1, a2, a3;
+            // the area weights of the hit point serve the interpolated normal AND the uv (Mesh::get_normal and
+            // Mesh::get_uv compute the same three numbers from the same inputs, src/shape/mesh.rs:105-161, :204-259)
+            if ((it_flags & RR_IF_SMOOTH) || (m.flags & RR_MF_ANY_TEX)) {
+                at = sc.attrs[it_tri_base + slot];
+                const f3 p = to_local_point(it, hit_point, gw);
                 area_weights(a, b, c, p, &a1, &a2, &a3);
+                have_weights = true;
+            }
+            if (it_flags & RR_IF_SMOOTH) {
                 f3 p1 = mk3(at.s0.x, at.s0.y, at.s0.z) * a1, p2 = mk3(at.s1.x, at.s1.y, at.s1.z) * a2, p3 = mk3(at.s2.x, at.s2.y, at.s2.z) * a3;
                 normal = to_world_normal(it, mk3(p1.x + p2.x + p3.x, p1.y + p2.y + p3.y, p1.z + p2.z + p3.z));
                 if (back) normal = -normal;
@@ -1133,7 +1142,11 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         // ---- uv (:749-754)
         bool has_uv = false; f2 uv; uv.x = 0.0f; uv.y = 0.0f;
         if (m.flags & RR_MF_ANY_TEX) {
-            uv = (it_flags & RR_IF_SPHERE) ? sphere_uv(it, hit_point, gw) : mesh_uv(sc, it, slot, hit_point, gw);
+            if (it_flags & RR_IF_SPHERE) uv = sphere_uv(it, hit_point, gw);
+            else if (have_weights && (__float_as_uint(at.s3.w) & 1u)) { // Mesh::get_uv with the weights from above
+                uv.x = (at.s0.w * a1 + at.s2.w * a2) + at.s3.y * a3;
+                uv.y = -((at.s1.w * a1 + at.s3.x * a2) + at.s3.z * a3);
+            }
             has_uv = true;
         }
         f3 surface_normal = normal;
