@@ -187,6 +187,104 @@ private:
     static void normalize(double* v) { const double n = std::sqrt(dot(v, v)); v[0] /= n; v[1] /= n; v[2] /= n; }
 };
 
+
+// A flat scene under construction: owns the arrays an rr_flat_scene points to.  Stands in for what the Rust shim of
+// INTEGRATION.md produces from `Scene` (items in Scene.items order, one texture-less material-cache entry per item).
+struct Material { // defaults of Material::new, reference src/shape/mod.rs:138-180
+    Vec3 ambient_color{0.0f, 0.0f, 0.0f}, base_color{1.0f, 1.0f, 1.0f}, specular_color{0.8f, 0.8f, 0.8f};
+    float alpha = 1.0f, shininess = 150.0f, reflectivity = 0.0f, refraction_index = 1.0f, normal_map_strength = 1.0f;
+    float shadow_softness = 0.01f, roughness = 0.0f;
+    int32_t texture[RR_TEX_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    bool texture_filtering_nearest = false, cast_shadow = true, receive_shadow = true, monte_carlo = true;
+    bool smooth_shading = true, reflection_only = false, backface_cullig = true;
+
+    rr_material c_struct(bool with_textures) const {
+        rr_material m;
+        std::memset(&m, 0, sizeof m);
+        const Vec3* src[3] = {&ambient_color, &base_color, &specular_color};
+        float* dst[3] = {m.ambient_color, m.base_color, m.specular_color};
+        for (int k = 0; k < 3; k++) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; }
+        m.alpha = alpha; m.shininess = shininess; m.reflectivity = reflectivity; m.refraction_index = refraction_index;
+        m.normal_map_strength = normal_map_strength; m.shadow_softness = shadow_softness; m.roughness = roughness;
+        for (int k = 0; k < RR_TEX_COUNT; k++) m.texture[k] = with_textures ? texture[k] : -1;
+        m.texture_filtering_nearest = texture_filtering_nearest; m.cast_shadow = cast_shadow; m.receive_shadow = receive_shadow;
+        m.monte_carlo = monte_carlo; m.smooth_shading = smooth_shading; m.reflection_only = reflection_only; m.backface_cullig = backface_cullig;
+        return m;
+    }
+};
+
+class FlatScene {
+public:
+    // a sphere of `radius` centred at `c` (Sphere::new + translation, reference src/shape/sphere.rs, src/shape/mod.rs:708-729)
+    uint32_t add_sphere(Vec3 c, float radius, const Material& mat, uint32_t id) {
+        rr_item it;
+        std::memset(&it, 0, sizeof it);
+        it.kind = RR_ITEM_SPHERE; it.id = id; it.mesh = -1; it.radius = radius;
+        identity(it.trans); identity(it.trans_inv);
+        it.trans[12] = c.x; it.trans[13] = c.y; it.trans[14] = c.z;
+        it.trans_inv[12] = -c.x; it.trans_inv[13] = -c.y; it.trans_inv[14] = -c.z;
+        for (int k = 0; k < 3; k++) { it.bbox_min[k] = -radius; it.bbox_max[k] = radius; }
+        it.visible = 1;
+        return push_item(it, mat);
+    }
+    // a triangle mesh in world space (identity transform); positions: 3 floats per vertex, indices: 3 per triangle
+    uint32_t add_mesh(const std::vector<float>& positions, const std::vector<uint32_t>& indices, const Material& mat, uint32_t id) {
+        mesh_pos_.push_back(positions); mesh_idx_.push_back(indices);
+        rr_item it;
+        std::memset(&it, 0, sizeof it);
+        it.kind = RR_ITEM_MESH; it.id = id; it.mesh = (int32_t)mesh_pos_.size() - 1;
+        identity(it.trans); identity(it.trans_inv);
+        for (int k = 0; k < 3; k++) { it.bbox_min[k] = 3.0e38f; it.bbox_max[k] = -3.0e38f; }
+        for (size_t v = 0; v + 2 < positions.size(); v += 3)
+            for (int k = 0; k < 3; k++) { it.bbox_min[k] = std::fmin(it.bbox_min[k], positions[v + k]); it.bbox_max[k] = std::fmax(it.bbox_max[k], positions[v + k]); }
+        it.visible = 1;
+        return push_item(it, mat);
+    }
+    void add_point_light(Vec3 pos, float intensity, Vec3 color = Vec3{1.0f, 1.0f, 1.0f}) {
+        rr_light l;
+        std::memset(&l, 0, sizeof l);
+        l.pos[0] = pos.x; l.pos[1] = pos.y; l.pos[2] = pos.z;
+        l.color[0] = color.x; l.color[1] = color.y; l.color[2] = color.z;
+        l.intensity = intensity; l.light_type = RR_LIGHT_POINT; l.enabled = 1;
+        lights_.push_back(l);
+    }
+    // valid while this object lives and is not modified
+    rr_flat_scene c_struct() {
+        meshes_.clear();
+        for (size_t i = 0; i < mesh_pos_.size(); i++) {
+            rr_mesh m;
+            std::memset(&m, 0, sizeof m);
+            m.positions = mesh_pos_[i].data(); m.indices = mesh_idx_[i].data();
+            m.n_vertices = (uint32_t)(mesh_pos_[i].size() / 3); m.n_triangles = (uint32_t)(mesh_idx_[i].size() / 3);
+            meshes_.push_back(m);
+        }
+        rr_flat_scene fs;
+        std::memset(&fs, 0, sizeof fs);
+        fs.abi_version = RR_ABI_VERSION;
+        fs.n_items = (uint32_t)items_.size(); fs.items = items_.data();
+        fs.n_meshes = (uint32_t)meshes_.size(); fs.meshes = meshes_.data();
+        fs.n_materials = (uint32_t)materials_.size(); fs.materials = materials_.data();
+        fs.n_lights = (uint32_t)lights_.size(); fs.lights = lights_.data();
+        return fs;
+    }
+
+private:
+    static void identity(float* m) { for (int i = 0; i < 16; i++) m[i] = (i % 5 == 0) ? 1.0f : 0.0f; }
+    uint32_t push_item(rr_item& it, const Material& mat) {
+        materials_.push_back(mat.c_struct(true));  // get_material()
+        materials_.push_back(mat.c_struct(false)); // get_material_cache_without_textures(), src/shape/mod.rs:769-772
+        it.material = (int32_t)materials_.size() - 2; it.material_cache = (int32_t)materials_.size() - 1;
+        items_.push_back(it);
+        return (uint32_t)items_.size() - 1;
+    }
+    std::vector<rr_item> items_;
+    std::vector<rr_material> materials_;
+    std::vector<rr_light> lights_;
+    std::vector<rr_mesh> meshes_;
+    std::vector<std::vector<float>> mesh_pos_;
+    std::vector<std::vector<uint32_t>> mesh_idx_;
+};
+
 // A scene resident on one GPU (rr_scene), owned.
 class DeviceScene {
 public:
