@@ -552,6 +552,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         return bytes ? hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
     };
     HIP_TRY(upload(s->nodes, all_nodes.data(), all_nodes.size() * sizeof(DNode)));
+    if (all_nodes4.size() >= (1u << 25)) return fail(RR_ERR_UNSUPPORTED, "%zu BVH4 nodes (node rows are addressed with 32-bit byte offsets)", all_nodes4.size());
     HIP_TRY(upload(s->nodes4, all_nodes4.data(), all_nodes4.size() * sizeof(DNode4)));
     tlas4.resize(std::max<size_t>(tlas4.size(), s->tlas_node_capacity)); // room for rebuilds after transform updates
     HIP_TRY(upload(s->tnodes4, tlas4.data(), tlas4.size() * sizeof(DNode4)));

@@ -244,12 +244,20 @@ RR_DEV bool slab2(float lox, float hix, float loy, float hiy, float loz, float h
 // rows is the near one for this ray's direction sign (row index 0/1), so that the step loads "near" and "far" rows
 // directly instead of ordering the two plane distances of every child with a min and a max.
 typedef float v2f __attribute__((ext_vector_type(2)));
-struct Slab4 { f3 o, inv; uint32_t sx, sy, sz; };
-RR_DEV Slab4 make_slab4(const SlabRay& r) {
+// Rows are addressed as (uniform node array) + 32-bit byte offset, so the loads take the scalar-base form and the
+// step needs one 32-bit add per row instead of 64-bit address arithmetic: off = (tree base + node) * 128 + row * 16.
+struct Slab4 { f3 o, inv; uint32_t nx, fx, ny, fy, nz, fz, cc; };
+RR_DEV Slab4 make_slab4(const SlabRay& r, uint32_t node_base) {
     Slab4 s; s.o = r.o; s.inv = r.inv;
-    s.sx = __float_as_uint(r.inv.x) >> 31; s.sy = __float_as_uint(r.inv.y) >> 31; s.sz = __float_as_uint(r.inv.z) >> 31;
+    const uint32_t sx = __float_as_uint(r.inv.x) >> 31, sy = __float_as_uint(r.inv.y) >> 31, sz = __float_as_uint(r.inv.z) >> 31;
+    const uint32_t b = node_base << 7;
+    s.nx = b + (sx << 4); s.fx = b + ((1u - sx) << 4);
+    s.ny = b + ((2u + sy) << 4); s.fy = b + ((3u - sy) << 4);
+    s.nz = b + ((4u + sz) << 4); s.fz = b + ((5u - sz) << 4);
+    s.cc = b + (6u << 4);
     return s;
 }
+RR_DEV float4 node_row(const DNode4* nodes, uint32_t byte_off) { return *(const float4*)((const char*)nodes + byte_off); }
 // (row - o) * inv for the four children of one plane row, as two packed pairs
 #define RR_ROW(row, oc, ic, lo_, hi_) const v2f lo_ = (v2f{row.x, row.y} - v2f{oc, oc}) * v2f{ic, ic}; \
                                       const v2f hi_ = (v2f{row.z, row.w} - v2f{oc, oc}) * v2f{ic, ic};
@@ -265,9 +273,11 @@ RR_DEV Slab4 make_slab4(const SlabRay& r) {
     }
 #define RR_NODE4_STEP(nodes4, s4, bound)                                                                       \
     {                                                                                                          \
-        RR_UTIL(2) const float4* np_ = (const float4*)((nodes4) + cur);                                        \
-        const float4 rnx = np_[(s4).sx], rfx = np_[1u - (s4).sx], rny = np_[2u + (s4).sy], rfy = np_[3u - (s4).sy];             \
-        const float4 rnz = np_[4u + (s4).sz], rfz = np_[5u - (s4).sz], cc = np_[6];                           \
+        RR_UTIL(2) const uint32_t no_ = (uint32_t)cur << 7;                                                    \
+        const float4 rnx = node_row(nodes4, no_ + (s4).nx), rfx = node_row(nodes4, no_ + (s4).fx);             \
+        const float4 rny = node_row(nodes4, no_ + (s4).ny), rfy = node_row(nodes4, no_ + (s4).fy);             \
+        const float4 rnz = node_row(nodes4, no_ + (s4).nz), rfz = node_row(nodes4, no_ + (s4).fz);             \
+        const float4 cc = node_row(nodes4, no_ + (s4).cc);                                                     \
         const float bound_ = (bound);                                                                          \
         const float inf_ = __builtin_inff();                                                                   \
         RR_ROW(rnx, (s4).o.x, (s4).inv.x, nx01, nx23) RR_ROW(rfx, (s4).o.x, (s4).inv.x, fx01, fx23)            \
@@ -289,9 +299,11 @@ RR_DEV Slab4 make_slab4(const SlabRay& r) {
 // the children are visited does not matter, so the hit children are pushed in slot order and the sort is skipped.
 #define RR_NODE4_STEP_ANY(nodes4, s4, bound)                                                                   \
     {                                                                                                          \
-        RR_UTIL(2) const float4* np_ = (const float4*)((nodes4) + cur);                                        \
-        const float4 rnx = np_[(s4).sx], rfx = np_[1u - (s4).sx], rny = np_[2u + (s4).sy], rfy = np_[3u - (s4).sy];             \
-        const float4 rnz = np_[4u + (s4).sz], rfz = np_[5u - (s4).sz], cc = np_[6];                           \
+        RR_UTIL(2) const uint32_t no_ = (uint32_t)cur << 7;                                                    \
+        const float4 rnx = node_row(nodes4, no_ + (s4).nx), rfx = node_row(nodes4, no_ + (s4).fx);             \
+        const float4 rny = node_row(nodes4, no_ + (s4).ny), rfy = node_row(nodes4, no_ + (s4).fy);             \
+        const float4 rnz = node_row(nodes4, no_ + (s4).nz), rfz = node_row(nodes4, no_ + (s4).fz);             \
+        const float4 cc = node_row(nodes4, no_ + (s4).cc);                                                     \
         const float bound_ = (bound);                                                                          \
         const float inf_ = __builtin_inff();                                                                   \
         RR_ROW(rnx, (s4).o.x, (s4).inv.x, nx01, nx23) RR_ROW(rfx, (s4).o.x, (s4).inv.x, fx01, fx23)            \
@@ -308,11 +320,11 @@ RR_DEV Slab4 make_slab4(const SlabRay& r) {
         if (h0) cur = __float_as_int(cc.x);                                                                    \
         else { sp--; cur = STK(sp); }                                                                          \
     }
-#define RR_BLAS_NODES(sc, it) ((sc).nodes4 + (it).node_base4)
+#define RR_BLAS_NODES(sc, it) ((sc).nodes4) // uniform; the tree's base is folded into the row offsets of the Slab4
 #define RR_BLAS_ROOT(it) ((it).root4)
 #define RR_BLAS_STEP(nodes, sr, bound) RR_NODE4_STEP(nodes, sr, bound)
 #define RR_BLAS_STEP_ANY(nodes, sr, bound) RR_NODE4_STEP_ANY(nodes, sr, bound)
-#define RR_BLAS_SLAB(r) make_slab4(make_slab((r).o, (r).d))
+#define RR_BLAS_SLAB(r) make_slab4(make_slab((r).o, (r).d), it.node_base4)
 typedef DNode4 BlasNode;
 typedef Slab4 BlasSlab;
 #else
@@ -543,7 +555,7 @@ RR_DEV void trace_closest_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, 
     // reference src/scene.rs:1715-1722; any conservative candidate set gives the same result)
 #if RR_TLAS4
     // the top level in the 4-wide form of the per-mesh trees, same step (sentinel-terminated stack)
-    const Slab4 ws = make_slab4(make_slab(o, d));
+    const Slab4 ws = make_slab4(make_slab(o, d), 0u);
     int sp = 1;
     STK(0) = RR_SENTINEL;
     int cur = sc.tlas_root4;
@@ -631,7 +643,7 @@ RR_DEV bool shadow_blocker_item(const DSceneView& sc, int idx, f3 o, f3 d, uint3
 RR_DEV bool trace_shadow_blockers(const DSceneView& sc, f3 o, f3 d, uint32_t depth, float limit, const ShadowSel& sel, int* s_stack) {
     const float bound = sel.key * 1.00001f + 1e-6f; // a blocker's box starts before the occluder's key
 #if RR_TLAS4
-    const Slab4 ws = make_slab4(make_slab(o, d));
+    const Slab4 ws = make_slab4(make_slab(o, d), 0u);
     int sp = 1;
     STK(0) = RR_SENTINEL;
     int cur = sc.tlas_root4;
@@ -665,7 +677,7 @@ RR_DEV void trace_shadow_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, f
     // an item whose world box starts beyond the light, or beyond the selected item's key, cannot matter
 #define RR_SHADOW_BOUND (sel->found ? fminf(limit, sel->key * 1.00001f + 1e-6f) : limit)
 #if RR_TLAS4
-    const Slab4 ws = make_slab4(make_slab(o, d));
+    const Slab4 ws = make_slab4(make_slab(o, d), 0u);
     int sp = 1;
     STK(0) = RR_SENTINEL;
     int cur = sc.tlas_root4;
