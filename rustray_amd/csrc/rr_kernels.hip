@@ -257,6 +257,7 @@ RR_DEV Slab4 make_slab4(const SlabRay& r, uint32_t node_base) {
     s.cc = b + (6u << 4);
     return s;
 }
+RR_DEV DTriX tri_at(const DTriX* tris, uint32_t byte_off) { return *(const DTriX*)((const char*)tris + byte_off); }
 RR_DEV float4 node_row(const DNode4* nodes, uint32_t byte_off) { return *(const float4*)((const char*)nodes + byte_off); }
 // (row - o) * inv for the four children of one plane row, as two packed pairs
 #define RR_ROW(row, oc, ic, lo_, hi_) const v2f lo_ = (v2f{row.x, row.y} - v2f{oc, oc}) * v2f{ic, ic}; \
@@ -362,7 +363,7 @@ struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool foun
         const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);                               \
         for (uint32_t i = 0; i < count; i++) {                                                                 \
             RR_UTIL(3)                                                                                         \
-            const DTriX tr = tris[first + i];                                                                  \
+            const DTriX tr = tri_at(sc.trix, (tri_base_ + first + i) << 6);                                    \
             float t; uint32_t side;                                                                            \
             if (ray_triangle(mk3(tr.t0.x, tr.t0.y, tr.t0.z), mk3(tr.t1.x, tr.t1.y, tr.t1.z),                   \
                              mk3(tr.t2.x, tr.t2.y, tr.t2.z), mk3(tr.t1.w, tr.t2.w, tr.t3.x), ray, &t, &side)) { \
@@ -379,7 +380,7 @@ struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool foun
         const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);                               \
         for (uint32_t i = 0; i < count; i++) {                                                                 \
             RR_UTIL(3)                                                                                         \
-            const DTriX tr = tris[first + i];                                                                  \
+            const DTriX tr = tri_at(sc.trix, (tri_base_ + first + i) << 6);                                    \
             float t; uint32_t side;                                                                            \
             if (ray_triangle(mk3(tr.t0.x, tr.t0.y, tr.t0.z), mk3(tr.t1.x, tr.t1.y, tr.t1.z),                   \
                              mk3(tr.t2.x, tr.t2.y, tr.t2.z), mk3(tr.t1.w, tr.t2.w, tr.t3.x), ray, &t, &side)) { \
@@ -394,7 +395,7 @@ RR_DEV void blas_closest(const DSceneView& sc, const DItem& it, const LRay& ray,
     TriBest best; best.found = false; best.t = RR_FLT_MAX; best.slot = 0; best.face = 0xffffffffu; best.side = 0u;
     const BlasSlab sr = RR_BLAS_SLAB(ray);
     const BlasNode* nodes = RR_BLAS_NODES(sc, it);
-    const DTriX* tris = sc.trix + it.tri_base;
+    const uint32_t tri_base_ = it.tri_base; // triangles, like node rows, are addressed as uniform base + 32-bit offset
     int sp = sp_base;
     STK(sp) = RR_SENTINEL; sp++;
     int cur = RR_BLAS_ROOT(it);
@@ -435,7 +436,7 @@ RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, flo
     bool any = false, within = false;
     const BlasSlab sr = RR_BLAS_SLAB(ray);
     const BlasNode* nodes = RR_BLAS_NODES(sc, it);
-    const DTriX* tris = sc.trix + it.tri_base;
+    const uint32_t tri_base_ = it.tri_base; // triangles, like node rows, are addressed as uniform base + 32-bit offset
     int sp = sp_base;
     STK(sp) = RR_SENTINEL; sp++;
     int cur = RR_BLAS_ROOT(it);
