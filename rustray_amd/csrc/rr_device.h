@@ -26,7 +26,9 @@ struct DNode4 { float4 q[8]; };
 // Depth limits enforced by the host builder, so the fixed LDS stack can never overflow: per level one
 // sentinel entry plus at most one pending sibling per inner node on the path, plus one scratch slot above the
 // top (the node step writes the far child before it knows whether it is needed).
+#ifndef RR_BLAS_MAX_DEPTH
 #define RR_BLAS_MAX_DEPTH 24
+#endif
 #define RR_TLAS_MAX_DEPTH 12
 #ifndef RR_STACK_DEPTH
 #define RR_STACK_DEPTH (RR_BLAS_MAX_DEPTH + RR_TLAS_MAX_DEPTH + 3)
