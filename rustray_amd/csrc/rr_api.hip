@@ -442,7 +442,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
                 hi[3 * (size_t)f + k] = std::max(a, std::max(b, c));
             }
         rr::BvhResult r;
-        static const uint32_t leaf_max = getenv("RR_LEAF_MAX") ? (uint32_t)std::min(4, std::max(1, atoi(getenv("RR_LEAF_MAX")))) : RR_MAX_LEAF_TRIS;
+        static const uint32_t leaf_max = getenv("RR_LEAF_MAX") ? (uint32_t)std::min(8, std::max(1, atoi(getenv("RR_LEAF_MAX")))) : RR_MAX_LEAF_TRIS;
         if (!rr::build_bvh(lo.data(), hi.data(), nt, leaf_max, s->blas_depth_limit, &r))
             return fail(RR_ERR_UNSUPPORTED, "mesh %u: BVH depth limit exceeded", mi);
         md[mi].node_base = (uint32_t)all_nodes.size();

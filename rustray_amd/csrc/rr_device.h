@@ -22,7 +22,7 @@ struct DNode4 { float4 q[8]; };
 
 #define RR_LEAF_FIRST(code) ((uint32_t)(code) & 0x0fffffffu)
 #define RR_LEAF_COUNT(code) ((((uint32_t)(code)) >> 28) + 1u)
-#define RR_MAX_LEAF_TRIS 4
+#define RR_MAX_LEAF_TRIS 8
 // Depth limits enforced by the host builder, so the fixed LDS stack can never overflow: per level one
 // sentinel entry plus at most one pending sibling per inner node on the path, plus one scratch slot above the
 // top (the node step writes the far child before it knows whether it is needed).
