@@ -864,6 +864,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
             if (!child_count) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise RR_SHADE_CHUNK");
             const DRayQueue qout = queue_at(child_base);
             for (uint64_t c0 = s0; c0 < s1; c0 += chunk) {
+                if (cancel && *cancel) { (void)hipStreamSynchronize(st); return fail(RR_ERR_CANCELLED, "cancelled"); }
                 const uint64_t c1 = std::min<uint64_t>(c0 + chunk, s1);
                 const int grid = (int)std::min<uint64_t>((c1 - c0 + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)shade_grid_max);
                 // shadow sub-queues: a shard gets the packets with (packet % RR_SQ_SHARDS == shard), L rays per hit at most

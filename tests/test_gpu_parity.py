@@ -410,3 +410,22 @@ def test_animation_run_equals_frame_by_frame_updates(hip):
         assert mgr.is_done()
     finally:
         rt.close()
+
+
+def test_cancel_flag_stops_a_frame(hip):
+    """`cancel` of rr_render (RendererManager::stop in the reference, src/renderer.rs:174-198): a flag that is already set
+    ends the call with RR_ERR_CANCELLED and the scene stays usable."""
+    import ctypes as C
+    from rustray_amd.flat import rr_frame
+    fs = load_scene("spheres")
+    cam = camera_for(fs, 64, 64).c_struct()
+    cfg = make_config(samples=4, monte_carlo=True, seed=1)
+    with hip.DeviceScene(fs, 0) as ds:
+        rgba = np.zeros((64, 64, 4), np.uint8)
+        fr = rr_frame(rgba.ctypes.data, None, None, None)
+        flag = C.c_int(1)
+        rc = hip.lib().rr_render(ds._h, C.byref(cam), C.byref(cfg), None, C.byref(fr), C.byref(flag))
+        assert rc == -6 and b"cancel" in hip.lib().rr_last_error()
+        flag.value = 0
+        assert hip.lib().rr_render(ds._h, C.byref(cam), C.byref(cfg), None, C.byref(fr), C.byref(flag)) == 0
+        assert np.array_equal(rgba, ds.render(cam, cfg, aux=False)["rgba"])
