@@ -285,6 +285,127 @@ private:
     std::vector<std::vector<uint32_t>> mesh_idx_;
 };
 
+// ---------------------------------------------------------------------------------------------------------
+// Keyframe animation: reference src/animation.rs:9-205 and Scene::apply_frame (src/scene.rs:1695-1713).  Only item
+// transforms change between frames, so a frame step on the device is rr_scene_update_transforms.
+// ---------------------------------------------------------------------------------------------------------
+struct Frame { // src/animation.rs:9-30; unset components are None in the reference
+    std::string object_name;
+    std::optional<Vec3> translation, rotation /* radians */, scale;
+};
+struct Keyframe { // src/animation.rs:35-52
+    uint64_t time = 0; // milliseconds
+    std::vector<Frame> objects;
+};
+
+class Animation {
+public:
+    bool enabled = false;
+    uint32_t fps = 25;
+    std::vector<Keyframe> keyframes;
+
+    bool has_initial_keyframe() const { return !keyframes.empty() && keyframes[0].time == 0; }               // :79-88
+    uint64_t get_frames_amount_to_render() const {                                                            // :90-98
+        const uint64_t last = keyframes.empty() ? 0 : keyframes.back().time;
+        return (uint64_t)std::floor((float)fps * ((float)last / 1000.0f));
+    }
+    bool has_animation() const {                                                                              // :100-103
+        return enabled && get_frames_amount_to_render() > 0 && has_initial_keyframe() && keyframes.size() >= 2;
+    }
+    bool frame_exists(uint64_t frame) const { return has_animation() && frame < get_frames_amount_to_render(); } // scene.rs:1690-1693
+
+    // :105-130: the keyframes around `frame` and the interpolation factor (NaN at the last keyframe: 1/0 * 0, as in Rust)
+    void get_keyframes_for_frame(uint64_t frame, const Keyframe** first, const Keyframe** last, double* factor) const {
+        const uint64_t timestamp = (uint64_t)std::floor((1000.0f / (float)fps) * (float)frame);
+        *first = *last = &keyframes[0];
+        for (size_t i = 0; i < keyframes.size(); i++)
+            if (keyframes[i].time <= timestamp) { *first = &keyframes[i]; *last = (i + 1 >= keyframes.size()) ? &keyframes[i] : &keyframes[i + 1]; }
+        const double pos = (double)(timestamp - (*first)->time), diff = (double)((*last)->time - (*first)->time);
+        *factor = 1.0 / diff * pos;
+    }
+
+    // :132-205: interpolated T * Rz * Ry * Rx * S of one object for `frame` (column-major), false if it has no keyframes
+    bool get_trans_for_frame(uint64_t frame, const std::string& object_name, float out[16]) const {
+        const Keyframe *kf, *kl; double factor;
+        get_keyframes_for_frame(frame, &kf, &kl, &factor);
+        const Frame *a = nullptr, *b = nullptr;
+        for (const Frame& f : kf->objects) if (f.object_name == object_name) { a = &f; break; }
+        for (const Frame& f : kl->objects) if (f.object_name == object_name) { b = &f; break; }
+        if (!a || !b) return false;
+        const float f = (float)factor;
+        auto lerp = [f](const std::optional<Vec3>& p, const std::optional<Vec3>& q, Vec3 d) {
+            if (!p || !q) return d;
+            return Vec3{p->x + f * (q->x - p->x), p->y + f * (q->y - p->y), p->z + f * (q->z - p->z)}; // helper::interpolate
+        };
+        const Vec3 t = lerp(a->translation, b->translation, Vec3{0.0f, 0.0f, 0.0f});
+        const Vec3 sc = lerp(a->scale, b->scale, Vec3{1.0f, 1.0f, 1.0f});
+        const Vec3 r = lerp(a->rotation, b->rotation, Vec3{0.0f, 0.0f, 0.0f});
+        get_transformation(t, sc, r, out);
+        return true;
+    }
+
+    // ShapeBasics::get_transformation on the identity (src/shape/mod.rs:708-729): T * Rz * Ry * Rx * S, f32, column-major
+    static void get_transformation(Vec3 t, Vec3 s, Vec3 r, float out[16]) {
+        float m[16]; ident(m);
+        float f[16];
+        ident(f); f[12] = t.x; f[13] = t.y; f[14] = t.z; mul(m, f);
+        rot(2, r.z, f); mul(m, f);
+        rot(1, r.y, f); mul(m, f);
+        rot(0, r.x, f); mul(m, f);
+        ident(f); f[0] = s.x; f[5] = s.y; f[10] = s.z; mul(m, f);
+        std::memcpy(out, m, sizeof m);
+    }
+
+    // ShapeBasics::calc_inverse (src/shape/mod.rs:763-767) of an affine matrix; evaluated in double, rounded to f32
+    static void inverse_affine(const float m[16], float out[16]) {
+        const double a = m[0], b = m[4], c = m[8], d = m[1], e = m[5], f = m[9], g = m[2], h = m[6], i = m[10];
+        const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+        const double r[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,
+                             (f * g - d * i) / det, (a * i - c * g) / det, (c * d - a * f) / det,
+                             (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det}; // row-major inverse of the 3x3
+        const double tx = m[12], ty = m[13], tz = m[14];
+        for (int k = 0; k < 16; k++) out[k] = 0.0f;
+        for (int rr = 0; rr < 3; rr++) {
+            for (int cc = 0; cc < 3; cc++) out[cc * 4 + rr] = (float)r[rr * 3 + cc];
+            out[12 + rr] = (float)(-(r[rr * 3] * tx + r[rr * 3 + 1] * ty + r[rr * 3 + 2] * tz));
+        }
+        out[15] = 1.0f;
+    }
+
+    // Scene::apply_frame on the arrays rr_scene_update_transforms takes: `trans` / `trans_inv` hold n_items * 16 floats
+    // (start from the items' own matrices); items named in the keyframes get their matrix REPLACED (apply_mat).
+    // Returns false when the reference would not touch the scene.
+    bool frame_transforms(const std::vector<std::string>& item_names, uint64_t frame, float* trans, float* trans_inv) const {
+        if (!has_animation() || frame > get_frames_amount_to_render()) return false;
+        for (size_t i = 0; i < item_names.size(); i++) {
+            float m[16];
+            if (get_trans_for_frame(frame, item_names[i], m)) std::memcpy(trans + 16 * i, m, sizeof m);
+            inverse_affine(trans + 16 * i, trans_inv + 16 * i);
+        }
+        return true;
+    }
+
+private:
+    static void ident(float* m) { for (int k = 0; k < 16; k++) m[k] = (k % 5 == 0) ? 1.0f : 0.0f; }
+    static void rot(int axis, float a, float* m) {
+        ident(m);
+        const float c = (float)std::cos((double)a), s = (float)std::sin((double)a);
+        if (axis == 0) { m[5] = c; m[9] = -s; m[6] = s; m[10] = c; }
+        else if (axis == 1) { m[0] = c; m[8] = s; m[2] = -s; m[10] = c; }
+        else { m[0] = c; m[4] = -s; m[1] = s; m[5] = c; }
+    }
+    static void mul(float* m, const float* f) { // m = m * f, f32 accumulation in nalgebra's column-axpy order
+        float o[16];
+        for (int c = 0; c < 4; c++)
+            for (int r = 0; r < 4; r++) {
+                float acc = m[r] * f[c * 4];
+                for (int k = 1; k < 4; k++) acc = acc + m[k * 4 + r] * f[c * 4 + k];
+                o[c * 4 + r] = acc;
+            }
+        std::memcpy(m, o, sizeof o);
+    }
+};
+
 // A scene resident on one GPU (rr_scene), owned.
 class DeviceScene {
 public:

@@ -80,3 +80,24 @@ extern "C" int rh_render(const rr_flat_scene* fs, int device, float fov, const f
     }
     return mgr.failed() ? -2 : 0;
 }
+
+// Animation::frame_transforms for a two-keyframe animation of ONE named object among `n_items` items
+// (names "item0", "item1", ...; the animated one is `animated`): tests the keyframe selection, the interpolation and
+// the transformation order against the Python mirror.
+extern "C" int rh_animation_frame(uint32_t fps, uint64_t t1_ms, const float* tr0, const float* rot0, const float* sc0,
+                                  const float* tr1, const float* rot1, const float* sc1, uint32_t n_items, uint32_t animated,
+                                  uint64_t frame, float* trans, float* trans_inv, uint64_t* frames_amount, int* exists) {
+    Animation an;
+    an.enabled = true; an.fps = fps;
+    const std::string name = "item" + std::to_string(animated);
+    Keyframe k0; k0.time = 0;
+    k0.objects.push_back(Frame{name, Vec3{tr0[0], tr0[1], tr0[2]}, Vec3{rot0[0], rot0[1], rot0[2]}, Vec3{sc0[0], sc0[1], sc0[2]}});
+    Keyframe k1; k1.time = t1_ms;
+    k1.objects.push_back(Frame{name, Vec3{tr1[0], tr1[1], tr1[2]}, Vec3{rot1[0], rot1[1], rot1[2]}, Vec3{sc1[0], sc1[1], sc1[2]}});
+    an.keyframes = {k0, k1};
+    std::vector<std::string> names;
+    for (uint32_t i = 0; i < n_items; i++) names.push_back("item" + std::to_string(i));
+    *frames_amount = an.get_frames_amount_to_render();
+    *exists = an.frame_exists(frame) ? 1 : 0;
+    return an.frame_transforms(names, frame, trans, trans_inv) ? 1 : 0;
+}

@@ -121,3 +121,37 @@ def test_renderer_manager_stop_ends_the_frame_early(shim):
     passes, rendered, done = int(stats[0]), int(stats[1]), int(stats[2])
     assert done == 0 and 2 <= passes < 16 and 0 < rendered < w * h
     assert out["rgba"][..., 3].min() == 255 and out["rgba"][..., :3].max() > 0
+
+
+def test_animation_frames_equal_the_python_mirror(shim):
+    """Animation (reference src/animation.rs) + Scene::apply_frame (src/scene.rs:1695-1713): keyframe selection, the
+    NaN factor at the last keyframe, interpolation and T * Rz * Ry * Rx * S agree with rustray_amd/animation.py."""
+    from rustray_amd.animation import Animation, Frame, Keyframe
+    from rustray_amd.flat import FlatScene, Item
+    F3 = C.c_float * 3
+    shim.rh_animation_frame.argtypes = [C.c_uint32, C.c_uint64, F3, F3, F3, F3, F3, F3, C.c_uint32, C.c_uint32, C.c_uint64,
+                                        C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+    tr0, rot0, sc0 = (0.0, 0.0, -10.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
+    tr1, rot1, sc1 = (1.0, 0.5, -9.0), (0.3, 2.0, -0.7), (1.4, 0.8, 1.1)
+    fs = FlatScene()
+    base = np.eye(4, dtype=np.float32); base[:3, 3] = (0.5, -1.0, 2.0)
+    for i in range(3):
+        fs.items.append(Item(kind=0, id=i + 1, material=0, material_cache=0, radius=1.0, trans=base.copy(), trans_inv=np.linalg.inv(base).astype(np.float32),
+                             bbox_min=(-1, -1, -1), bbox_max=(1, 1, 1), name=f"item{i}"))
+    an = Animation(True, 7, [Keyframe(0, [Frame("item1", tr0, rot0, sc0)]), Keyframe(1500, [Frame("item1", tr1, rot1, sc1)])])
+    for frame in (0, 3, 9, 10, 11):
+        trans = np.stack([base.T.copy() for _ in range(3)]).astype(np.float32)      # column-major, as the ABI takes them
+        inv = np.zeros_like(trans)
+        amount, exists = C.c_uint64(), C.c_int()
+        touched = shim.rh_animation_frame(7, 1500, F3(*tr0), F3(*rot0), F3(*sc0), F3(*tr1), F3(*rot1), F3(*sc1), 3, 1, frame,
+                                          trans.ctypes.data, inv.ctypes.data, C.byref(amount), C.byref(exists))
+        ref = an.frame_transforms(fs, frame)
+        assert amount.value == an.get_frames_amount_to_render() == 10 and bool(exists.value) == an.frame_exists(frame)
+        assert bool(touched) == (ref is not None)
+        if ref is None:
+            continue
+        rt, ri = ref
+        got_t = np.transpose(trans, (0, 2, 1)); got_i = np.transpose(inv, (0, 2, 1))
+        assert np.allclose(got_t, rt, rtol=2e-6, atol=2e-6, equal_nan=True), frame
+        assert np.allclose(got_i, ri, rtol=2e-5, atol=2e-5, equal_nan=True), frame
+        assert np.array_equal(got_t[0], base) and np.array_equal(got_t[2], base)        # items without keyframes keep their matrix
