@@ -525,6 +525,20 @@ public:
         if (object_id) *object_id = objects_;
     }
 
+    // Run::post_processing (src/run.rs:588-600) -> run_post_processing (src/post_processing.rs:123-181) on the finished
+    // frame: outline on object-id edges, then cavity shading from the normal buffer.  Returns the new image.
+    std::vector<uint8_t> post_processing(bool cavity, bool outline, int device = 0) {
+        std::vector<uint8_t> in; std::vector<float> nr; std::vector<uint32_t> ids;
+        frame(&in, &nr, nullptr, &ids);
+        std::vector<uint8_t> out(in.size());
+        if (rr_post_process((uint32_t)width_, (uint32_t)height_, cavity ? 1 : 0, outline ? 1 : 0, in.data(), nr.data(), ids.data(), out.data(), device) != RR_OK) {
+            std::lock_guard<std::mutex> lk(frame_mu_);
+            error_ = rr_last_error();
+            return in;
+        }
+        return out;
+    }
+
     void wait() { join(); } // not in the reference: block until the frame is done or stopped
     bool failed() const { return failed_; }
     std::string last_error() { std::lock_guard<std::mutex> lk(frame_mu_); return error_; }

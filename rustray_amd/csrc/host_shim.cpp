@@ -74,6 +74,10 @@ extern "C" int rh_render(const rr_flat_scene* fs, int device, float fov, const f
     std::memcpy(ids, id.data(), id.size() * 4);
     stats[0] = mgr.passes(); stats[1] = mgr.get_rendered_pixels(); stats[2] = mgr.is_done() ? 1 : 0; stats[3] = drained;
     stats[4] = mgr.check_and_get_elapsed_time();
+    if (stop_after_passes == -1) { // the caller wants the post-processed image (cavity + outline)
+        const std::vector<uint8_t> pp = mgr.post_processing(true, true, device);
+        std::memcpy(rgba, pp.data(), pp.size());
+    }
     if (pick_out) {
         auto p = rt->pick(pick_x, pick_y);
         pick_out[0] = p ? 1.0f : 0.0f; pick_out[1] = p ? (float)p->first : 0.0f; pick_out[2] = p ? p->second : 0.0f;

@@ -155,3 +155,17 @@ def test_animation_frames_equal_the_python_mirror(shim):
         assert np.allclose(got_t, rt, rtol=2e-6, atol=2e-6, equal_nan=True), frame
         assert np.allclose(got_i, ri, rtol=2e-5, atol=2e-5, equal_nan=True), frame
         assert np.array_equal(got_t[0], base) and np.array_equal(got_t[2], base)        # items without keyframes keep their matrix
+
+
+@pytest.mark.gpu
+def test_renderer_manager_post_processing_equals_the_abi_call(shim):
+    """Run::post_processing (reference src/run.rs:588-600) through the C++ layer == rr_post_process on the same frame."""
+    fs = load_scene("spheres_room")
+    w, h = 96, 64
+    cam = camera_for(fs, w, h)
+    cfg = make_config(samples=4, monte_carlo=True, seed=4)
+    with capi.DeviceScene(fs, 0) as ds:
+        ref = ds.render(cam.c_struct(), cfg)
+    want = capi.post_process(ref["rgba"], ref["normal"], ref["object_id"], cavity=True, outline=True)
+    rc, out, _, _ = _render(shim, fs, cam, cfg, w, h, min_passes=2, stop_after=-1)
+    assert rc == 0 and np.array_equal(out["rgba"], want) and not np.array_equal(want, ref["rgba"])
