@@ -94,7 +94,7 @@ struct rr_scene {
     bool profiling = false;
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
-    hipEvent_t frame_a = nullptr, frame_b = nullptr;
+    hipEvent_t frame_a = nullptr, frame_b = nullptr, count_ready = nullptr;
     hipStream_t last_stream = nullptr; // frame state (queues, accumulators) is shared: frames on different streams are serialised
     uint32_t* h_count = nullptr; // pinned: level sizes read back between depth levels
 };
@@ -581,6 +581,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     HIP_TRY(s->counters.reserve(RR_CNT_WORDS * 8));
     HIP_TRY(hipEventCreate(&s->frame_a));
     HIP_TRY(hipEventCreate(&s->frame_b));
+    HIP_TRY(hipEventCreateWithFlags(&s->count_ready, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void**)&s->h_count, 64, hipHostMallocDefault));
     const char* prof = getenv("RR_PROFILE");
     s->profiling = prof && atoi(prof) != 0;
@@ -602,6 +603,7 @@ extern "C" void rr_scene_destroy(rr_scene* s) {
     for (auto& t : s->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     if (s->frame_a) (void)hipEventDestroy(s->frame_a);
     if (s->frame_b) (void)hipEventDestroy(s->frame_b);
+    if (s->count_ready) (void)hipEventDestroy(s->count_ready);
     if (s->h_count) (void)hipHostFree(s->h_count);
     delete s;
 }
@@ -879,6 +881,13 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
                     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, fr, s->region_xy.as<uint32_t>(), qin, count,
                                        (uint32_t)c0, (uint32_t)c1, qout, child_count, SQ, sq_counts, segcap, acc, counters);
                 }
+                // The size of the next level is final once the slice's last shade chunk has run: its read-back is enqueued
+                // BEFORE that chunk's shadow kernel, so the host learns it (and enqueues the next level) while the shadow
+                // rays are still being traced, instead of leaving the device idle for a host round trip per level.
+                if (spawns && c1 == s1) {
+                    HIP_TRY(hipMemcpyAsync(s->h_count, child_count, 4, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipEventRecord(s->count_ready, st));
+                }
                 if (L) {
                     ScopedTimer t(s, st, 1);
                     const uint64_t sq_ub = (c1 - c0) * L;
@@ -887,8 +896,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
                 }
             }
             if (!spawns) continue;
-            HIP_TRY(hipMemcpyAsync(s->h_count, child_count, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipEventSynchronize(s->count_ready));
             const uint64_t m = *s->h_count;
             if (m > M - child_base) return fail(RR_ERR_DEVICE, "internal: level %u holds %llu rays, room for %llu", d + 1, (unsigned long long)m, (unsigned long long)(M - child_base));
             if (m > 0) { const int rc2 = run_level(d + 1, child_base, m, child_count); if (rc2 != RR_OK) return rc2; }
