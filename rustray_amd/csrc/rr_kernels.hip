@@ -712,9 +712,10 @@ RR_DEV void trace_shadow_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, f
 // ---------------------------------------------------------------------------
 // textures: reference src/raytracing.rs:629-675, src/shape/mod.rs:510-629
 // ---------------------------------------------------------------------------
-RR_DEV float4 texel(const DSceneView& sc, const DTexture& t, uint32_t x, uint32_t y) {
+// `lut`: the u8 -> f32 table (c_u8_to_f32, or a workgroup's copy of it in LDS: four dependent reads per texel)
+RR_DEV float4 texel(const DSceneView& sc, const DTexture& t, uint32_t x, uint32_t y, const float* lut = c_u8_to_f32) {
     uint32_t p = sc.texels[t.offset + (uint64_t)y * t.width + x];
-    return make_float4(c_u8_to_f32[p & 255u], c_u8_to_f32[(p >> 8) & 255u], c_u8_to_f32[(p >> 16) & 255u], c_u8_to_f32[p >> 24]);
+    return make_float4(lut[p & 255u], lut[(p >> 8) & 255u], lut[(p >> 16) & 255u], lut[p >> 24]);
 }
 RR_DEV uint32_t tex_wrap(float val, uint32_t bound) {
     int32_t sb = (int32_t)bound;
@@ -725,7 +726,7 @@ RR_DEV uint32_t tex_wrap(float val, uint32_t bound) {
     return (w < 0) ? (uint32_t)(w + sb) : (uint32_t)w;
 }
 RR_DEV float lerp1(float a, float b, float f) { return a + f * (b - a); } // helper::interpolate
-RR_DEV float4 tex_bilinear(const DSceneView& sc, const DTexture& t, float u, float v) {
+RR_DEV float4 tex_bilinear(const DSceneView& sc, const DTexture& t, float u, float v, const float* lut = c_u8_to_f32) {
     uint32_t width = t.width, height = t.height;
     float x = u * (float)width, y = v * (float)height;
     if (x < 0.0f) x = x + (float)width;
@@ -737,7 +738,7 @@ RR_DEV float4 tex_bilinear(const DSceneView& sc, const DTexture& t, float u, flo
     if (x1 >= width) x1 = width - 1u;
     if (y1 >= height) y1 = height - 1u;
     float fx = x - (float)x0, fy = y - (float)y0;
-    float4 p0 = texel(sc, t, x0, y0), p1 = texel(sc, t, x1, y0), p2 = texel(sc, t, x0, y1), p3 = texel(sc, t, x1, y1);
+    float4 p0 = texel(sc, t, x0, y0, lut), p1 = texel(sc, t, x1, y0, lut), p2 = texel(sc, t, x0, y1, lut), p3 = texel(sc, t, x1, y1, lut);
     float4 a = make_float4(lerp1(p0.x, p1.x, fx), lerp1(p0.y, p1.y, fx), lerp1(p0.z, p1.z, fx), lerp1(p0.w, p1.w, fx));
     float4 b = make_float4(lerp1(p2.x, p3.x, fx), lerp1(p2.y, p3.y, fx), lerp1(p2.z, p3.z, fx), lerp1(p2.w, p3.w, fx));
     return make_float4(lerp1(a.x, b.x, fy), lerp1(a.y, b.y, fy), lerp1(a.z, b.z, fy), lerp1(a.w, b.w, fy));
@@ -750,8 +751,9 @@ struct MatR {
     float alpha, shininess, reflectivity, refraction_index, normal_map_strength, shadow_softness, roughness;
     uint32_t flags;
     const DMaterial* p;
+    const float* lut; // u8 -> f32 table of the workgroup (LDS)
 };
-RR_DEV MatR load_material(const DMaterial* p) {
+RR_DEV MatR load_material(const DMaterial* p, const float* lut) {
     const float4* q = (const float4*)p;
     const float4 a = q[0], b = q[1], c = q[2], d = q[3];
     MatR m;
@@ -759,14 +761,14 @@ RR_DEV MatR load_material(const DMaterial* p) {
     m.base = mk3(b.x, b.y, b.z); m.shininess = b.w;
     m.specular = mk3(c.x, c.y, c.z); m.reflectivity = c.w;
     m.refraction_index = d.x; m.normal_map_strength = d.y; m.shadow_softness = d.z; m.roughness = d.w;
-    m.flags = p->flags; m.p = p;
+    m.flags = p->flags; m.p = p; m.lut = lut;
     return m;
 }
 RR_DEV bool tex_color(const DSceneView& sc, const MatR& m, bool has_uv, f2 uv, int slot, float4* out) {
     if (!(m.flags & (RR_MF_TEX_SLOT0 << slot)) || !has_uv) return false; // slot bit = index >= 0 and width > 0
     const DTexture t = sc.textures[m.p->tex[slot]];
-    if (m.flags & RR_MF_NEAREST) *out = texel(sc, t, tex_wrap(uv.x, t.width), tex_wrap(uv.y, t.height));
-    else *out = tex_bilinear(sc, t, uv.x, uv.y);
+    if (m.flags & RR_MF_NEAREST) *out = texel(sc, t, tex_wrap(uv.x, t.width), tex_wrap(uv.y, t.height), m.lut);
+    else *out = tex_bilinear(sc, t, uv.x, uv.y, m.lut);
     return true;
 }
 // get_tex_color: false = None
@@ -1070,6 +1072,9 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
     // (one atomic per workgroup iteration: a single append counter sustains ~90 returning atomics per microsecond, which
     // made it THE limiter of this kernel on scenes where most hits spawn children)
     __shared__ uint32_t s_child_n[2][RR_BLOCK / RR_WAVE];
+    __shared__ float s_lut[256]; // the u8 -> f32 table next to the lanes: a texel decodes with four LDS reads
+    s_lut[threadIdx.x] = c_u8_to_f32[threadIdx.x];
+    __syncthreads();
     __shared__ uint32_t s_child_base[2];
     const uint32_t wave_in_block = threadIdx.x / RR_WAVE;
     uint32_t parity = 0;
@@ -1104,7 +1109,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         const float thr = r0.w;
         const DItem& it = sc.items[item_idx];
         const uint32_t it_flags = it.flags, it_tri_base = it.tri_base, it_id = it.id; // register copies (see MatR)
-        const MatR m = load_material(&sc.materials[it.material]);
+        const MatR m = load_material(&sc.materials[it.material], s_lut);
         const f3 ro = mk3(r0.x, r0.y, r0.z), rd = mk3(r1.x, r1.y, r1.z);
         const float hit_dist = __uint_as_float(hit.x);
         const f3 hit_point = ro + (rd * hit_dist);
