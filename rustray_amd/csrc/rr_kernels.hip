@@ -1206,7 +1206,6 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         if (tex_color(sc, m, has_uv, uv, 4, &tc)) alpha *= tc.x;
 
         // ---- everything after the light loop that does not depend on it (:922-991)
-        const float kr = fresnel(rd, surface_normal, m.refraction_index);
         float reflectivity = m.reflectivity;
         if (tex_color(sc, m, has_uv, uv, 7, &tc)) reflectivity = tc.x;
         const bool may_recurse = depth <= fr.max_recursion;
@@ -1237,7 +1236,11 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         const float g = (1.0f - fog_amount) * ao;
         const float w_light = thr * ((1.0f - reflectivity) * a_mul * g);
         const float w_refl = thr * (reflectivity * a_mul * g);
-        const float w_refr = thr * (((kr < 1.0f) ? ((1.0f - kr) * (1.0f - alpha)) : (1.0f - alpha)) * g);
+        float w_refr = 0.0f; // only a refraction child carries it: fresnel() is evaluated for the hits that spawn one
+        if (spawn_refr) {
+            const float kr = fresnel(rd, surface_normal, m.refraction_index);
+            w_refr = thr * (((kr < 1.0f) ? ((1.0f - kr) * (1.0f - alpha)) : (1.0f - alpha)) * g);
+        }
 
         // ---- constant part: fog colour and ambient / emissive (:977-994)
         {
