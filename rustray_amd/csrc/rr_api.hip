@@ -338,7 +338,7 @@ static int build_tlas(rr_scene* s, const std::vector<rr_item>& items, std::vecto
         r4.root = *root;
         int pending = 0;
         tlas4->clear();
-        *root4 = rr::collapse_bvh4(r4, s->tlas_depth_limit, tlas4, &pending);
+        *root4 = rr::collapse_bvh4(r4, s->tlas_depth_limit, false, tlas4, &pending);
         if (pending > s->tlas_depth_limit) return fail(RR_ERR_UNSUPPORTED, "top level: BVH4 stack bound exceeded");
     }
     *tlas = std::move(r.nodes);
@@ -454,7 +454,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
 #if RR_BVH4
         int pending = 0;
         md[mi].node_base4 = (uint32_t)all_nodes4.size();
-        md[mi].root4 = rr::collapse_bvh4(r, s->blas_depth_limit, &all_nodes4, &pending);
+        md[mi].root4 = rr::collapse_bvh4(r, s->blas_depth_limit, true, &all_nodes4, &pending);
         if (pending > s->blas_depth_limit) return fail(RR_ERR_UNSUPPORTED, "mesh %u: BVH4 stack bound exceeded", mi);
 #else
         md[mi].node_base4 = 0; md[mi].root4 = r.root;

@@ -167,6 +167,7 @@ struct Collapse {
     std::vector<int> height; // BVH2 inner levels below (and including) each node
     std::vector<DNode4>* out;
     int limit, max_pending;
+    bool greedy;
     int h_of(int32_t code) const { return code < 0 ? 0 : height[code]; }
     int fill_heights(int32_t n) {
         if (n < 0) return 0;
@@ -182,18 +183,43 @@ struct Collapse {
         struct Slot { int32_t code; Box4 box; };
         const int32_t ch[2] = {child_of(b2.nodes[n2], 0), child_of(b2.nodes[n2], 1)};
         Slot slots[4]; int ns = 0;
-        // which children to open: both, one, or none
-        static const int plans[4][2] = {{1, 1}, {1, 0}, {0, 1}, {0, 0}};
-        for (int p = 0; p < 4; p++) {
-            ns = 0;
-            bool ok = true;
-            for (int k = 0; k < 2; k++) {
-                if (plans[p][k] && ch[k] >= 0) {
-                    for (int g = 0; g < 2; g++) { slots[ns].code = child_of(b2.nodes[ch[k]], g); slots[ns].box = box_of(b2.nodes[ch[k]], g); ns++; }
-                } else { slots[ns].code = ch[k]; slots[ns].box = box_of(b2.nodes[n2], k); ns++; }
+        if (!greedy) {
+            // open both children, one, or none: the first plan whose subtrees all fit the stack budget
+            static const int plans[4][2] = {{1, 1}, {1, 0}, {0, 1}, {0, 0}};
+            for (int p = 0; p < 4; p++) {
+                ns = 0;
+                bool ok = true;
+                for (int k = 0; k < 2; k++) {
+                    if (plans[p][k] && ch[k] >= 0) {
+                        for (int g = 0; g < 2; g++) { slots[ns].code = child_of(b2.nodes[ch[k]], g); slots[ns].box = box_of(b2.nodes[ch[k]], g); ns++; }
+                    } else { slots[ns].code = ch[k]; slots[ns].box = box_of(b2.nodes[n2], k); ns++; }
+                }
+                for (int s = 0; s < ns; s++) ok = ok && (pending + (ns - 1) + h_of(slots[s].code) <= limit);
+                if (ok) break;
             }
-            for (int s = 0; s < ns; s++) ok = ok && (pending + (ns - 1) + h_of(slots[s].code) <= limit);
-            if (ok) break;
+        } else {
+            // Greedy by surface area: while a slot is free, open the inner child with the largest box (this may go three
+            // BVH2 levels down on one side), as long as every resulting subtree still fits the stack budget.
+            for (int k = 0; k < 2; k++) { slots[ns].code = ch[k]; slots[ns].box = box_of(b2.nodes[n2], k); ns++; }
+            auto area = [](const Box4& bx) { const float dx = bx.hi[0] - bx.lo[0], dy = bx.hi[1] - bx.lo[1], dz = bx.hi[2] - bx.lo[2]; return dx * dy + dy * dz + dz * dx; };
+            auto fits = [&](const Slot* sl, int n) { for (int s = 0; s < n; s++) if (pending + (n - 1) + h_of(sl[s].code) > limit) return false; return true; };
+            bool closed[4] = {false, false, false, false}; // a slot that could not be opened stays as it is
+            while (ns < 4) {
+                int pick = -1; float best = -1.0f;
+                for (int s = 0; s < ns; s++)
+                    if (slots[s].code >= 0 && !closed[s]) { const float ar = area(slots[s].box); if (ar > best) { best = ar; pick = s; } }
+                if (pick < 0) break;
+                Slot trial[4]; int nt = 0;
+                for (int s = 0; s < ns; s++) {
+                    if (s == pick) { for (int g = 0; g < 2; g++) { trial[nt].code = child_of(b2.nodes[slots[s].code], g); trial[nt].box = box_of(b2.nodes[slots[s].code], g); nt++; } }
+                    else trial[nt++] = slots[s];
+                }
+                if (!fits(trial, nt)) { closed[pick] = true; continue; }
+                bool nc[4] = {false, false, false, false};
+                for (int s = 0, t = 0; s < ns; s++) { if (s == pick) t += 2; else nc[t++] = closed[s]; }
+                for (int s = 0; s < nt; s++) { slots[s] = trial[s]; closed[s] = nc[s]; }
+                ns = nt;
+            }
         }
         const int32_t idx = (int32_t)out->size();
         out->emplace_back();
@@ -216,9 +242,9 @@ struct Collapse {
 };
 } // namespace
 
-int32_t collapse_bvh4(const BvhResult& b2, int limit, std::vector<DNode4>* out, int* max_pending) {
+int32_t collapse_bvh4(const BvhResult& b2, int limit, bool greedy, std::vector<DNode4>* out, int* max_pending) {
     std::vector<DNode4> local; // child indices are relative to the first node of this tree, like the BVH2 form
-    Collapse c{b2, std::vector<int>(b2.nodes.size(), 0), &local, limit, 0};
+    Collapse c{b2, std::vector<int>(b2.nodes.size(), 0), &local, limit, 0, greedy};
     c.fill_heights(b2.root);
     const int32_t root = c.rec(b2.root, 0);
     out->insert(out->end(), local.begin(), local.end());

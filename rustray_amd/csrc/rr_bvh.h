@@ -16,7 +16,9 @@ struct BvhResult {
 // BVH2 -> BVH4: a node adopts its grandchildren wherever a depth-first walk with `limit` stack entries still
 // reaches every leaf below (see rr_bvh.cpp).  Appends the nodes to *out (child indices relative to the tree's first
 // node), returns the root (node index or leaf code) and the worst-case number of pending entries.
-int32_t collapse_bvh4(const BvhResult& b2, int limit, std::vector<DNode4>* out, int* max_pending);
+// `greedy`: open the child with the largest box first (per-mesh trees: -4 % on a 320 k-triangle mesh); otherwise both
+// children of a node are opened (the top level: greedy measured +2.5 % there).
+int32_t collapse_bvh4(const BvhResult& b2, int limit, bool greedy, std::vector<DNode4>* out, int* max_pending);
 
 // boxes_lo / boxes_hi: n * 3 floats.  Returns false if the depth limit could not be met.
 bool build_bvh(const float* boxes_lo, const float* boxes_hi, uint32_t n, uint32_t max_leaf, int max_depth, BvhResult* out);
