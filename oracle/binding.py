@@ -58,6 +58,8 @@ def lib():
         _LIB.rro_tex_interpolate.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         _LIB.rro_stdrng_u32.argtypes = [C.c_uint64, C.c_int, C.c_void_p]
         _LIB.rro_chacha_block.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+        _LIB.rro_set_shot_era.argtypes = [C.c_int]
+        _LIB.rro_set_shot_era.restype = None
     return _LIB
 
 

@@ -110,6 +110,7 @@ typedef struct rro_counters {
 } rro_counters;
 }
 
+static int g_shot_era = 0; // see rro_set_shot_era
 static thread_local rro_counters* tl_cnt = nullptr;
 static thread_local int tl_kind = 0; // 0 closest, 1 shadow
 #define CNT(field, n) do { if (tl_cnt) tl_cnt->field += (n); } while (0)
@@ -980,8 +981,10 @@ static Shade get_color_depth_normal_id(const RenderCtx& rc, Ray ray, uint16_t de
             }
             if (!in_light) {
                 const rr_item& shadow_obj = fs->items[sh.item];
-                float shadow_source_alpha = material.alpha;
                 const rr_material& som = fs->materials[shadow_obj.material];
+                // HEAD takes the RECEIVER's material.alpha (:898).  g_shot_era (rro_set_shot_era, archaeology for
+                // tests/test_ref_shots.py only) takes the OCCLUDER's, which is what the 2022-05 README renderings show.
+                float shadow_source_alpha = g_shot_era ? som.alpha : material.alpha;
                 V3 shadow_hit_point = shadow_ray.origin + (shadow_ray.dir * sh.toi);
                 // the reference evaluates the RECEIVER's get_uv with the occluder's face id (:905)
                 if (som.texture[RR_TEX_ALPHA] >= 0 && fs->textures[som.texture[RR_TEX_ALPHA]].width > 0) {
@@ -1206,6 +1209,11 @@ struct StdRng {
 };
 
 extern "C" {
+
+// Archaeology switch for the README-rendering pins (tests/test_ref_shots.py): 0 = the source at HEAD (default, what
+// the product implements); 1 = shadow attenuation by the occluder's alpha, as the binary that made the 2022-05
+// renderings evidently did.  Never set by anything but that test.
+void rro_set_shot_era(int era) { g_shot_era = era; }
 
 int rro_sample_table(uint16_t samples, uint16_t* xy_out, uint32_t* cell_size_out) {
     uint32_t cs = cell_size_for(samples);
