@@ -14,10 +14,24 @@ de-interleaves them; the timed region is bracketed by barrier +
 torch.cuda.synchronize() and the MAX over ranks is taken.  A ray = one
 Raytracing::trace call of the reference (primary, reflection, refraction, shadow).
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel: k_trace_closest,
-algorithmic bytes per SURVEY.md 8d from the instrumented oracle, launch time from
-HIP events on the launch stream) and `cpu_baseline` (the C++ restatement in oracle/
-timed on the host cores over a bounded sample of the same frame).
+The timed frame is the CONTRACT frame: RGBA8 plus the aux buffers PixelData carries
+(normal, depth, object id: reference src/raytracing.rs:57-70), resident in HBM at the end.
+Extra keys (rank 0, N = 1): `rgba_only_ms` (aux buffers not requested), `rr_render_host_ms`
+(the same frame through rr_render into host memory, PCIe included), and `other_configs`
+(helmet_syn 1280x720x64, lotus_syn 1280x720x512 + DOF: stand-ins for BASELINE configs C3 / C5).
+
+Rank 0 prints ONE JSON line with `roofline` and `cpu_baseline` (the C++ restatement in
+oracle/ timed on the host cores over a bounded sample of the same frame).
+
+`roofline`: the dominant kernel k_trace_closest walks a BVH that lives in L2 / Infinity
+Cache (130 MB), so HBM is NOT what bounds it (measured: 8 % of HBM peak); what it runs out
+of is vector-instruction issue slots and the latency that keeps them empty.  `bound` is
+therefore "valu_issue": achieved = VALU wave-instructions per ray (SQ_INSTS_VALU of the
+committed profiles/r*_sq_counters.json, a property of code + scene) x rays per launch /
+launch duration measured LIVE with HIP events on the launch stream; peak = 1024 SIMDs x
+2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md: SIMD-32).  The SURVEY 8d
+algorithmic bytes and the PMC-measured HBM bytes are kept beside it as `algorithmic_gbs`,
+`traffic` and `hbm_measured_frac`, never as `frac`.
 """
 import argparse
 import json
@@ -31,28 +45,40 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # 1024 SIMD-32 x 2.4 GHz / 2 issue cycles per wave64 VALU instruction = 1228.8 G wave-inst/s
 
 
-def build_workload(args):
+def build_workload(scene, width, height, spp, monte_carlo=1):
     from rustray_amd import synthetic
     from rustray_amd.camera import Camera
     from rustray_amd.flat import make_config
     from tests.helpers import load_scene
-    if args.scene == "sponza_syn":
+    if scene == "sponza_syn":
         fs = synthetic.sponza_syn()
-    elif args.scene == "lotus_syn":
+    elif scene == "lotus_syn":
         fs = synthetic.lotus_syn()
-    elif args.scene == "helmet_syn":
+    elif scene == "helmet_syn":
         fs = synthetic.helmet_syn()
     else:
-        fs = load_scene(args.scene)
+        fs = load_scene(scene)
     st = dict(fs.meta["camera"])
-    st["width"], st["height"] = args.width, args.height
+    st["width"], st["height"] = width, height
     cam = Camera.from_state(st)
     cfgd = fs.meta.get("config") or {}
-    cfg = make_config(samples=args.spp, monte_carlo=bool(args.monte_carlo), seed=0, max_recursion=6,
+    cfg = make_config(samples=spp, monte_carlo=bool(monte_carlo), seed=0, max_recursion=6,
                       focal_length=cfgd.get("focal_length", 1.0), aperture_size=cfgd.get("aperture_size", 1.0))
     return fs, cam, cfg
+
+
+def newest_profile(pattern):
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not paths:
+        return None, None
+    try:
+        return json.load(open(paths[-1])), os.path.relpath(paths[-1], ROOT)
+    except Exception:  # noqa: BLE001
+        return None, None
 
 
 def usable_cpus() -> int:
@@ -102,6 +128,38 @@ def cpu_baseline(fs, cam, args):
                 ms_per_frame_scaled=dt * 1000.0 * args.spp / args.cpu_spp, bvh_build_s=t_build), ab
 
 
+def extras(args, ds, camc, cfg, step, fence):
+    """Rank 0, N = 1: the same frame without aux buffers, the same frame through rr_render into host memory, and one
+    frame each of the stand-ins for BASELINE configs C3 / C5."""
+    from rustray_amd import capi
+    out = {}
+
+    def timed(fn, reps=2):
+        fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        fence()
+        return (time.perf_counter() - t0) * 1000.0 / reps
+    out["rgba_only_ms"] = timed(lambda: step(aux=False))
+    out["rr_render_host_ms"] = timed(lambda: ds.render(camc, cfg, aux=True))   # RGBA8 + aux over PCIe into pageable host arrays
+    out["rr_render_host_rgba_only_ms"] = timed(lambda: ds.render(camc, cfg, aux=False))
+    other = {}
+    for scene, spp in (("helmet_syn", 64), ("lotus_syn", 512)):
+        fs2, cam2, cfg2 = build_workload(scene, args.width, args.height, spp, 1)
+        with capi.DeviceScene(fs2, ds.device) as d2:
+            c2 = cam2.c_struct()
+            ms = timed(lambda: d2.render(c2, cfg2, aux=True), reps=1)
+            st = d2.stats()
+        rays = st["primary_rays"] + st["secondary_rays"] + st["shadow_rays"]
+        other[f"{scene} {args.width}x{args.height} {spp}spp" + (" +DOF" if cfg2.aperture_size > 1.0 else "")] = {
+            "ms_per_frame_host": ms, "ms_per_frame_device": st["ms_total"], "mrays_per_s": rays / (st["ms_total"] * 1e-3) / 1e6,
+            "rays": rays, "items": len(fs2.items), "triangles": fs2.n_triangles_instanced()}
+    out["other_configs"] = other
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +172,8 @@ def main():
     ap.add_argument("--monte-carlo", type=int, default=1)
     ap.add_argument("--cpu-spp", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip rgba_only / rr_render_host / other_configs (profiling runs)")
+    ap.add_argument("--rgba-only", action="store_true", help="developer A/B: time the frame without the aux buffers")
     ap.add_argument("--tile", default="32x8")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     args = ap.parse_args()
@@ -139,15 +199,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
 
-    fs, cam, cfg = build_workload(args)
+    fs, cam, cfg = build_workload(args.scene, args.width, args.height, args.spp, args.monte_carlo)
     tw, th = [int(v) for v in args.tile.split("x")]
     tf = TiledFrame(args.width, args.height, rank, world, tw, th)
     ds = capi.DeviceScene(fs, local_rank)  # scene replicated on every GPU, resident before timing
     ds.set_profiling(True)
     camc = cam.c_struct()
 
-    def step():
-        parts = render_region_torch(ds, camc, cfg, tf, aux=False)
+    def step(aux=not args.rgba_only):
+        parts = render_region_torch(ds, camc, cfg, tf, aux=aux)
         return tf.gather(parts, use_device_kernel=True, via_cpu=(args.dist_backend == "gloo"))
 
     def fence():
@@ -188,6 +248,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{fs.name} {args.width}x{args.height} {args.spp}spp monte_carlo={args.monte_carlo} max_recursion=6 "
                                    "(synthetic stand-in for scene/sponza.json: the .glb asset is not available offline)",
+                       "outputs": "RGBA8 only (--rgba-only)" if args.rgba_only else "RGBA8 + normal + depth + object_id (PixelData), resident in HBM",
                        "items": len(fs.items), "triangles": fs.n_triangles_instanced(),
                        "tiling": f"{tw}x{th} tiles interleaved over {world} rank(s), RGBA8 gather to rank 0",
                        "ray_definition": "one Raytracing::trace call: primary + reflection + refraction + shadow"},
@@ -205,34 +266,42 @@ def main():
             st = dict(fs.meta["camera"]); st["width"], st["height"] = 320, 180
             small = argparse.Namespace(**vars(args)); small.cpu_spp = 1
             _, ab = cpu_baseline(fs, _Cam.from_state(st), small)
-        # roofline of the dominant kernel (rank 0's launches): algorithmic bytes / launch time
+        # roofline of the dominant kernel (rank 0's launches), see the module docstring
         n_closest_r0 = acc["primary_rays"] + acc["secondary_rays"]
-        if ab is not None and acc["launches_trace_closest"] > 0:
-            bpr = ab["bytes_per_closest_ray"]
+        if acc["launches_trace_closest"] > 0:
             launches = acc["launches_trace_closest"]
             avg_ms = acc["ms_trace_closest"] / launches
-            bytes_per_launch = bpr * n_closest_r0 / launches
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            import glob
-            tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
-            if tpaths:   # PMC passes are separate rocprofv3 runs (tools/profile_round.sh); the newest committed summary is quoted
-                try:
-                    traffic = json.load(open(tpaths[-1])).get("k_trace_closest_bytes_per_launch")
-                except Exception:  # noqa: BLE001
-                    traffic = None
-            result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                                  "kernel": "k_trace_closest", "launches": launches, "avg_launch_ms": avg_ms,
-                                  "algorithmic_bytes_per_ray": bpr, "rays_per_launch": n_closest_r0 / launches,
-                                  "whole_frame_bytes_per_ray": ab["bytes_per_ray"],
-                                  "whole_frame_achieved_gbs": ab["bytes_per_ray"] * rays / elapsed / 1e9}
+            rays_per_launch = n_closest_r0 / launches
+            sq, sq_path = newest_profile("r*_sq_counters.json")
+            hbm, hbm_path = newest_profile("r*_hbm_traffic.json")
+            roof = {"bound": "valu_issue", "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "kernel": "k_trace_closest", "launches": launches,
+                    "avg_launch_ms": avg_ms, "rays_per_launch": rays_per_launch, "achieved": None, "frac": None, "traffic": None}
+            if sq and sq.get("workload", "").startswith(f"{fs.name} {args.width}x{args.height} {args.spp}spp"):
+                vpr = sq["kernels"]["k_trace_closest"]["valu_insts_per_ray"]
+                roof["achieved"] = vpr * rays_per_launch / (avg_ms * 1e-3) / 1e9
+                roof["frac"] = roof["achieved"] / VALU_PEAK_GINST
+                roof["valu_wave_insts_per_ray"] = vpr
+                roof["sq_counters"] = sq_path
+                roof["sq_wait_any_frac_of_wave_cycles"] = sq["kernels"]["k_trace_closest"].get("wait_any_frac")
+            if hbm:
+                roof["traffic"] = hbm.get("k_trace_closest_bytes_per_launch")
+                roof["traffic_source"] = hbm_path
+                if roof["traffic"]:
+                    roof["hbm_measured_frac"] = roof["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if ab is not None:
+                bpr = ab["bytes_per_closest_ray"]
+                roof["algorithmic_bytes_per_ray"] = bpr
+                roof["algorithmic_gbs"] = bpr * rays_per_launch / (avg_ms * 1e-3) / 1e9   # cache-served: may exceed HBM peak
+                roof["whole_frame_bytes_per_ray"] = ab["bytes_per_ray"]
+            result["roofline"] = roof
         result["kernel_ms_per_frame"] = {"k_trace_closest": acc["ms_trace_closest"] / args.steps,
                                          "k_trace_shadow": acc["ms_trace_shadow"] / args.steps,
                                          "k_shade": acc["ms_shade"] / args.steps,
                                          "frame_device_ms": acc["ms_total"] / args.steps}
         if frame is not None:
             result["frame_checksum"] = int(frame["rgba"].to(torch.int64).sum().item())
+        if world == 1 and not args.no_extras:
+            result.update(extras(args, ds, camc, cfg, step, fence))
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

@@ -48,6 +48,12 @@ typedef enum rr_status {
  * (reference default is 6, src/raytracing.rs:124). */
 #define RR_MAX_RECURSION 16u
 
+/* Largest RaytracingConfig::samples accepted.  The reference computes the sub-sample cell size as
+ * `(samples + 2).next_power_of_two() / 2` in u16 arithmetic (src/raytracing.rs:297), which overflows from
+ * 32767 samples on, and shuffles cell_size^2 cells; 16382 is the last count whose table (16384^2 cells) is
+ * still built in reasonable time. */
+#define RR_MAX_SAMPLES 16382u
+
 /* TextureType order of reference src/shape/mod.rs:633-643. */
 enum {
     RR_TEX_BASE = 0,
@@ -238,6 +244,19 @@ typedef struct rr_frame_stats {
     uint64_t sliced_levels; /* depth levels whose children did not fit behind them in the ray arena at once */
 } rr_frame_stats;
 
+/* Execution knobs of the device path.  None of them changes a single output bit (fixed-point accumulation makes
+ * the frame independent of batching, chunking and grouping); they exist for memory-constrained hosts, for tests
+ * that force the slicing paths, and for profiling.  All zero = automatic.  The library reads NO environment
+ * variables. */
+typedef struct rr_tuning {
+    uint32_t struct_size;        /* sizeof(rr_tuning) */
+    uint32_t sample_group;       /* primary samples of one pixel per 64-ray packet: 0 = largest that divides `samples`, else 1, 2, 4 ... 64 */
+    uint64_t queue_budget_bytes; /* ray-arena memory: 0 = a quarter of the free HBM, at most 64 GB */
+    uint64_t shade_chunk_rays;   /* rays shaded per launch: 0 = 64 Mi (minimum 65536) */
+    uint32_t kernel_timing;      /* non-zero: per-launch HIP events fill the ms_* fields of rr_frame_stats */
+    uint32_t _pad;
+} rr_tuning;
+
 typedef struct rr_scene rr_scene; /* opaque */
 
 /* Number of HIP devices visible; 0 if none (never fails). */
@@ -256,6 +275,16 @@ void rr_scene_destroy(rr_scene* scene);
  * reference ShapeBasics::apply_mat, src/shape/mod.rs:748-753; Scene::apply_frame
  * src/scene.rs:1695-1713).  trans / trans_inv hold n_items * 16 floats. */
 int rr_scene_update_transforms(rr_scene* scene, const float* trans, const float* trans_inv);
+
+/* Replace every material in place (GUI edits between frames: reference Material::apply_diff, src/shape/mod.rs:182-242,
+ * driven from src/run.rs:1132-1133).  `materials` holds the same n_materials records, in the same order, as the
+ * flat scene the handle was created from (full materials and material caches alike); texture slots may name any
+ * texture uploaded at creation.  Meshes, acceleration structures and texture images are not touched. */
+int rr_scene_update_materials(rr_scene* scene, const rr_material* materials, uint32_t n_materials);
+
+/* Execution knobs (see rr_tuning). */
+int rr_scene_set_tuning(rr_scene* scene, const rr_tuning* tuning);
+int rr_scene_get_tuning(const rr_scene* scene, rr_tuning* tuning);
 
 /* The reference's per-pixel sub-sample table (src/raytracing.rs:290-313):
  * cell_size^2 cells shuffled with StdRng::seed_from_u64(0), truncated to

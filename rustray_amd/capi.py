@@ -12,14 +12,16 @@ import subprocess
 
 import numpy as np
 
-from .flat import (rr_camera, rr_config, rr_flat_scene, rr_frame, rr_frame_stats, rr_pick_result, rr_region)
+from .flat import (rr_camera, rr_config, rr_flat_scene, rr_frame, rr_frame_stats, rr_material, rr_pick_result, rr_region, rr_tuning)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RUSTRAY_HIP_LIB") or os.path.join(_HERE, "librustray_hip.so")  # override: developer A/B builds
 _LIB = None
 
+# every symbol include/rustray_hip.h declares (tests/test_abi.py checks the list against the header)
 EXPORTS = ["rr_device_count", "rr_last_error", "rr_scene_create", "rr_scene_destroy", "rr_scene_update_transforms",
-           "rr_sample_table", "rr_render", "rr_region_pixel_count", "rr_render_region_device",
+           "rr_scene_update_materials", "rr_scene_set_tuning", "rr_scene_get_tuning",
+           "rr_sample_table", "rr_render", "rr_render_progressive", "rr_region_pixel_count", "rr_render_region_device",
            "rr_deinterleave_device", "rr_pick", "rr_scene_last_stats", "rr_post_process", "rr_post_process_device"]
 
 
@@ -65,7 +67,9 @@ def lib():
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.rr_pick.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.c_int, C.c_int, C.POINTER(rr_pick_result)]
         L.rr_scene_last_stats.argtypes = [C.c_void_p, C.POINTER(rr_frame_stats)]
-        L.rr_scene_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.rr_scene_update_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.rr_scene_set_tuning.argtypes = [C.c_void_p, C.POINTER(rr_tuning)]
+        L.rr_scene_get_tuning.argtypes = [C.c_void_p, C.POINTER(rr_tuning)]
         L.rr_post_process.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.rr_post_process_device.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.rr_math_probe.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
@@ -192,8 +196,24 @@ class DeviceScene:
         _check(lib().rr_pick(self._h, C.byref(cam), x, y, C.byref(r)))
         return r
 
+    def update_materials(self, materials):
+        """rr_scene_update_materials: `materials` = the flat scene's material list (same length and order), edited."""
+        arr = (rr_material * len(materials))(*[m.c_struct() if hasattr(m, "c_struct") else m for m in materials])
+        _check(lib().rr_scene_update_materials(self._h, arr, len(materials)))
+
+    def set_tuning(self, **kw):
+        """rr_scene_set_tuning: sample_group, queue_budget_bytes, shade_chunk_rays, kernel_timing (others keep their value)."""
+        t = rr_tuning()
+        _check(lib().rr_scene_get_tuning(self._h, C.byref(t)))
+        for k, v in kw.items():
+            if k not in ("sample_group", "queue_budget_bytes", "shade_chunk_rays", "kernel_timing"):
+                raise TypeError(f"unknown tuning field {k}")
+            setattr(t, k, int(v))
+        t.struct_size = C.sizeof(rr_tuning)
+        _check(lib().rr_scene_set_tuning(self._h, C.byref(t)))
+
     def set_profiling(self, on: bool):
-        _check(lib().rr_scene_set_profiling(self._h, 1 if on else 0))
+        self.set_tuning(kernel_timing=1 if on else 0)
 
     def stats(self) -> dict:
         st = rr_frame_stats()

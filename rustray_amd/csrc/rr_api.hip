@@ -50,9 +50,17 @@ static int fail(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------
 // device buffer helper
 // ---------------------------------------------------------------------------
+// Owns one device allocation (freed on destruction: every exit path of rr_scene_create and the scratch buffers of
+// rr_pick / rr_post_process release what they hold).  Move-only.
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; } return *this; }
+    ~DevBuf() { release(); }
     hipError_t reserve(size_t n) {
         if (n <= bytes) return hipSuccess;
         if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
@@ -65,6 +73,7 @@ struct DevBuf {
 };
 
 struct TimedLaunch { hipEvent_t a, b; int kind; };
+struct ItemHost { uint32_t kind; int32_t material, material_cache; bool visible, flip_normals, mesh_has_normals; };
 
 struct rr_scene {
     int device = 0;
@@ -74,6 +83,9 @@ struct rr_scene {
     DevBuf items, nodes, nodes4, tnodes4, tris, trix, attrs, face_slot, materials, textures, texels, lights;
     DSceneView view{};
     std::vector<DItem> h_items;
+    std::vector<ItemHost> item_host; // what rr_scene_update_materials needs to rebuild the item flag words
+    std::vector<uint32_t> tex_width;
+    uint32_t n_materials = 0;
     uint32_t n_enabled_lights = 0;
     uint32_t tlas_node_capacity = 0;
     int tlas_depth_limit = RR_TLAS_MAX_DEPTH, blas_depth_limit = RR_BLAS_MAX_DEPTH; // shares of the traversal stack, see rr_scene_create
@@ -97,6 +109,18 @@ struct rr_scene {
     hipEvent_t frame_a = nullptr, frame_b = nullptr, count_ready = nullptr;
     hipStream_t last_stream = nullptr; // frame state (queues, accumulators) is shared: frames on different streams are serialised
     uint32_t* h_count = nullptr; // pinned: level sizes read back between depth levels
+    rr_tuning tuning{};          // rr_scene_set_tuning; all zero = automatic
+    std::vector<uint16_t> table_cache; uint16_t table_samples = 0; // built-in sub-sample table of the last sample count
+    // every device buffer is a DevBuf member (freed by its destructor, on the scene's device)
+    ~rr_scene() {
+        (void)hipSetDevice(device);
+        for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
+        for (auto& t : timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+        if (frame_a) (void)hipEventDestroy(frame_a);
+        if (frame_b) (void)hipEventDestroy(frame_b);
+        if (count_ready) (void)hipEventDestroy(count_ready);
+        if (h_count) (void)hipHostFree(h_count);
+    }
 };
 
 static const uint32_t POOL_WORDS = 1u << 22; // per-batch counters (level sizes, fetch heads, shadow shard counts): 16 MB, zeroed per batch
@@ -165,6 +189,7 @@ uint32_t cell_size_of(uint16_t samples) {
 
 extern "C" int rr_sample_table(uint16_t samples, uint16_t* xy_out, uint32_t* cell_size_out) {
     if (!xy_out && samples) return fail(RR_ERR_INVALID_ARGUMENT, "rr_sample_table: xy_out is NULL");
+    if (samples > RR_MAX_SAMPLES) return fail(RR_ERR_UNSUPPORTED, "samples %u > %u", (unsigned)samples, RR_MAX_SAMPLES);
     uint32_t cs = cell_size_of(samples);
     std::vector<uint32_t> cells((size_t)cs * cs);
     size_t k = 0;
@@ -284,6 +309,40 @@ static int validate_scene(const rr_flat_scene* fs) {
     return RR_OK;
 }
 
+// Material (reference src/shape/mod.rs:95-134) -> device record; has_texture = the slot names an image of width > 0
+static DMaterial make_dmaterial(const rr_material& m, const std::vector<uint32_t>& tex_width) {
+    DMaterial d;
+    memset(&d, 0, sizeof d);
+    for (int k = 0; k < 3; k++) { d.ambient[k] = m.ambient_color[k]; d.base[k] = m.base_color[k]; d.specular[k] = m.specular_color[k]; }
+    d.alpha = m.alpha; d.shininess = m.shininess; d.reflectivity = m.reflectivity; d.refraction_index = m.refraction_index;
+    d.normal_map_strength = m.normal_map_strength; d.shadow_softness = m.shadow_softness; d.roughness = m.roughness;
+    bool any = false;
+    uint32_t slots = 0u;
+    for (int k = 0; k < RR_TEX_COUNT; k++) {
+        d.tex[k] = m.texture[k];
+        if (m.texture[k] >= 0 && tex_width[m.texture[k]] > 0) { any = true; slots |= RR_MF_TEX_SLOT0 << k; }
+    }
+    d.flags = slots | (m.texture_filtering_nearest ? RR_MF_NEAREST : 0u) | (m.receive_shadow ? RR_MF_RECEIVE_SHADOW : 0u) |
+              (m.monte_carlo ? RR_MF_MONTE_CARLO : 0u) | (any ? RR_MF_ANY_TEX : 0u);
+    return d;
+}
+
+// The flag word of an item: what Raytracing::trace reads of the texture-less material cache (src/raytracing.rs:450-458),
+// intersect_b_box's `solid` (src/shape/mesh.rs:51-59) and the occluder-alpha-map test of the shadow code (:899-912).
+static uint32_t item_flags(const ItemHost& it, const rr_material& cache, const rr_material& full, const std::vector<uint32_t>& tex_width) {
+    uint32_t f = 0;
+    if (it.visible) f |= RR_IF_VISIBLE;
+    if (it.flip_normals) f |= RR_IF_FLIP_NORMALS;
+    if (cache.alpha > 0.0f) f |= RR_IF_CACHE_ALPHA_POS;
+    if (cache.cast_shadow) f |= RR_IF_CACHE_CAST_SHADOW;
+    if (cache.reflection_only) f |= RR_IF_CACHE_REFL_ONLY;
+    if (!(cache.alpha < 1.0f) && cache.backface_cullig) f |= RR_IF_SOLID_BASE; // the cache never has textures
+    if (full.texture[RR_TEX_ALPHA] >= 0 && tex_width[full.texture[RR_TEX_ALPHA]] > 0) f |= RR_IF_OCCLUDER_ALPHA_TEX;
+    if (it.kind == RR_ITEM_SPHERE) f |= RR_IF_SPHERE;
+    else if (cache.smooth_shading && it.mesh_has_normals) f |= RR_IF_SMOOTH;
+    return f;
+}
+
 static void fill_item_matrices(DItem& d, const float* trans, const float* inv) {
     // rows of the column-major matrices
     d.inv0 = make_float4(inv[0], inv[4], inv[8], inv[12]);
@@ -317,6 +376,11 @@ static void world_box(const rr_item& it, float* lo, float* hi) {
 static int build_tlas(rr_scene* s, const std::vector<rr_item>& items, std::vector<DNode>* tlas, int32_t* root,
                       std::vector<DNode4>* tlas4, int32_t* root4) {
     uint32_t n = (uint32_t)items.size();
+    if (n == 0) { // empty scene: every walk ends at once
+        tlas->clear(); tlas4->clear();
+        *root = *root4 = (int32_t)0x80000000; // RR_SENTINEL
+        return RR_OK;
+    }
     std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
     for (uint32_t i = 0; i < n; i++) world_box(items[i], &lo[3 * (size_t)i], &hi[3 * (size_t)i]);
     rr::BvhResult r;
@@ -382,23 +446,10 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     if (!dtex.empty()) HIP_TRY(hipMemcpy(s->textures.p, dtex.data(), dtex.size() * sizeof(DTexture), hipMemcpyHostToDevice));
 
     // ---- materials
+    s->tex_width.resize(fs->n_textures);
+    for (uint32_t i = 0; i < fs->n_textures; i++) s->tex_width[i] = fs->textures[i].width;
     std::vector<DMaterial> dmat(fs->n_materials);
-    for (uint32_t i = 0; i < fs->n_materials; i++) {
-        const rr_material& m = fs->materials[i];
-        DMaterial& d = dmat[i];
-        memset(&d, 0, sizeof d);
-        for (int k = 0; k < 3; k++) { d.ambient[k] = m.ambient_color[k]; d.base[k] = m.base_color[k]; d.specular[k] = m.specular_color[k]; }
-        d.alpha = m.alpha; d.shininess = m.shininess; d.reflectivity = m.reflectivity; d.refraction_index = m.refraction_index;
-        d.normal_map_strength = m.normal_map_strength; d.shadow_softness = m.shadow_softness; d.roughness = m.roughness;
-        bool any = false;
-        uint32_t slots = 0u;
-        for (int k = 0; k < RR_TEX_COUNT; k++) {
-            d.tex[k] = m.texture[k];
-            if (m.texture[k] >= 0 && fs->textures[m.texture[k]].width > 0) { any = true; slots |= RR_MF_TEX_SLOT0 << k; } // has_texture: width > 0
-        }
-        d.flags = slots | (m.texture_filtering_nearest ? RR_MF_NEAREST : 0u) | (m.receive_shadow ? RR_MF_RECEIVE_SHADOW : 0u) |
-                  (m.monte_carlo ? RR_MF_MONTE_CARLO : 0u) | (any ? RR_MF_ANY_TEX : 0u);
-    }
+    for (uint32_t i = 0; i < fs->n_materials; i++) dmat[i] = make_dmaterial(fs->materials[i], s->tex_width);
     HIP_TRY(s->materials.reserve(std::max<size_t>(dmat.size(), 1) * sizeof(DMaterial)));
     if (!dmat.empty()) HIP_TRY(hipMemcpy(s->materials.p, dmat.data(), dmat.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
 
@@ -442,8 +493,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
                 hi[3 * (size_t)f + k] = std::max(a, std::max(b, c));
             }
         rr::BvhResult r;
-        static const uint32_t leaf_max = getenv("RR_LEAF_MAX") ? (uint32_t)std::min(8, std::max(1, atoi(getenv("RR_LEAF_MAX")))) : RR_MAX_LEAF_TRIS;
-        if (!rr::build_bvh(lo.data(), hi.data(), nt, leaf_max, s->blas_depth_limit, &r))
+        if (!rr::build_bvh(lo.data(), hi.data(), nt, RR_MAX_LEAF_TRIS, s->blas_depth_limit, &r))
             return fail(RR_ERR_UNSUPPORTED, "mesh %u: BVH depth limit exceeded", mi);
         md[mi].node_base = (uint32_t)all_nodes.size();
         md[mi].tri_base = (uint32_t)all_tris.size();
@@ -504,6 +554,8 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
 
     // ---- items
     s->h_items.resize(fs->n_items);
+    s->item_host.resize(fs->n_items);
+    s->n_materials = fs->n_materials;
     bool general_w = false;
     for (uint32_t i = 0; i < fs->n_items; i++) {
         const rr_item& it = fs->items[i];
@@ -517,22 +569,15 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         d.radius = it.radius;
         d.id = it.id;
         d.material = it.material;
-        uint32_t f = 0;
-        if (it.visible) f |= RR_IF_VISIBLE;
-        if (it.flip_normals) f |= RR_IF_FLIP_NORMALS;
-        if (cache.alpha > 0.0f) f |= RR_IF_CACHE_ALPHA_POS;
-        if (cache.cast_shadow) f |= RR_IF_CACHE_CAST_SHADOW;
-        if (cache.reflection_only) f |= RR_IF_CACHE_REFL_ONLY;
-        if (!(cache.alpha < 1.0f) && cache.backface_cullig) f |= RR_IF_SOLID_BASE; // the cache never has textures
-        if (full.texture[RR_TEX_ALPHA] >= 0 && fs->textures[full.texture[RR_TEX_ALPHA]].width > 0) f |= RR_IF_OCCLUDER_ALPHA_TEX;
-        if (it.kind == RR_ITEM_SPHERE) {
-            f |= RR_IF_SPHERE;
-        } else {
+        ItemHost& ih = s->item_host[i];
+        ih = ItemHost{it.kind, it.material, it.material_cache, it.visible != 0, it.flip_normals != 0, false};
+        if (it.kind != RR_ITEM_SPHERE) {
             const MeshDev& m = md[it.mesh];
             d.node_base = m.node_base; d.root = m.root; d.tri_base = m.tri_base; d.n_tris = m.n_tris;
             d.node_base4 = m.node_base4; d.root4 = m.root4;
-            if (cache.smooth_shading && m.has_normals) f |= RR_IF_SMOOTH;
+            ih.mesh_has_normals = m.has_normals;
         }
+        const uint32_t f = item_flags(ih, cache, full, s->tex_width);
         d.flags = f;
     }
 
@@ -583,8 +628,6 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     HIP_TRY(hipEventCreate(&s->frame_b));
     HIP_TRY(hipEventCreateWithFlags(&s->count_ready, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void**)&s->h_count, 64, hipHostMallocDefault));
-    const char* prof = getenv("RR_PROFILE");
-    s->profiling = prof && atoi(prof) != 0;
     *out = s.release();
     return RR_OK;
 }
@@ -593,19 +636,7 @@ extern "C" void rr_scene_destroy(rr_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();
-    DevBuf* all[] = {&s->items, &s->nodes, &s->tris, &s->attrs, &s->face_slot, &s->materials, &s->textures, &s->texels, &s->lights,
-                     &s->acc_rgb, &s->acc_normal, &s->acc_depth, &s->acc_id, &s->region_xy, &s->trace_order, &s->sample_xy, &s->pool, &s->counters};
-    for (DevBuf* b : all) b->release();
-    for (int k = 0; k < 4; k++) s->arena[k].release();
-    for (int k = 0; k < 4; k++) s->tmp_out[k].release();
-    for (int k = 0; k < 3; k++) s->sq[k].release();
-    for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
-    for (auto& t : s->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
-    if (s->frame_a) (void)hipEventDestroy(s->frame_a);
-    if (s->frame_b) (void)hipEventDestroy(s->frame_b);
-    if (s->count_ready) (void)hipEventDestroy(s->count_ready);
-    if (s->h_count) (void)hipHostFree(s->h_count);
-    delete s;
+    delete s; // ~rr_scene: events, pinned memory; ~DevBuf: every device buffer
 }
 
 extern "C" int rr_scene_update_transforms(rr_scene* s, const float* trans, const float* trans_inv) {
@@ -640,12 +671,38 @@ extern "C" int rr_scene_update_transforms(rr_scene* s, const float* trans, const
     return RR_OK;
 }
 
+// Material edits between frames (GUI sliders: reference src/run.rs:1132-1133 writes through Material::apply_diff,
+// src/shape/mod.rs:182-242): every material record is replaced and the item flag words derived from the material
+// caches are rebuilt; geometry, acceleration structures and texture images stay as uploaded.
+extern "C" int rr_scene_update_materials(rr_scene* s, const rr_material* materials, uint32_t n_materials) {
+    if (!s || !materials) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (n_materials != s->n_materials) return fail(RR_ERR_INVALID_ARGUMENT, "%u materials, the scene was created with %u", n_materials, s->n_materials);
+    for (uint32_t i = 0; i < n_materials; i++)
+        for (int k = 0; k < RR_TEX_COUNT; k++)
+            if (materials[i].texture[k] >= (int32_t)s->tex_width.size()) return fail(RR_ERR_INVALID_ARGUMENT, "material %u texture slot %d = %d out of range", i, k, materials[i].texture[k]);
+    for (const ItemHost& ih : s->item_host)
+        for (int k = 0; k < RR_TEX_COUNT; k++)
+            if (materials[ih.material_cache].texture[k] >= 0)
+                return fail(RR_ERR_INVALID_ARGUMENT, "material %d is a material cache and must not carry textures (reference src/shape/mod.rs:769-772)", ih.material_cache);
+    HIP_TRY(hipSetDevice(s->device));
+    std::vector<DMaterial> dmat(n_materials);
+    for (uint32_t i = 0; i < n_materials; i++) dmat[i] = make_dmaterial(materials[i], s->tex_width);
+    for (size_t i = 0; i < s->item_host.size(); i++)
+        s->h_items[i].flags = item_flags(s->item_host[i], materials[s->item_host[i].material_cache], materials[s->item_host[i].material], s->tex_width);
+    HIP_TRY(hipDeviceSynchronize());
+    if (n_materials) HIP_TRY(hipMemcpy(s->materials.p, dmat.data(), dmat.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
+    if (!s->h_items.empty()) HIP_TRY(hipMemcpy(s->items.p, s->h_items.data(), s->h_items.size() * sizeof(DItem), hipMemcpyHostToDevice));
+    return RR_OK;
+}
+
 // ---------------------------------------------------------------------------
 // frame
 // ---------------------------------------------------------------------------
 static int check_frame_args(const rr_scene* s, const rr_camera* cam, const rr_config* cfg) {
     if (!s || !cam || !cfg) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
     if (cfg->samples == 0) return fail(RR_ERR_INVALID_ARGUMENT, "samples must be >= 1");
+    if (cfg->samples > RR_MAX_SAMPLES) return fail(RR_ERR_UNSUPPORTED, "samples %u > %u", (unsigned)cfg->samples, RR_MAX_SAMPLES);
     if (cfg->max_recursion > RR_MAX_RECURSION) return fail(RR_ERR_UNSUPPORTED, "max_recursion %u > %u", cfg->max_recursion, RR_MAX_RECURSION);
     if (cam->width == 0 || cam->height == 0 || cam->width > 65535u || cam->height > 65535u) return fail(RR_ERR_INVALID_ARGUMENT, "bad frame size %ux%u", cam->width, cam->height);
     if (!finite16(cam->projection_inverse) || !finite16(cam->view_inverse)) return fail(RR_ERR_INVALID_ARGUMENT, "non-finite camera matrix");
@@ -728,15 +785,17 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     fr.n_region_pixels = npix;
 
     // ---- sample table
-    std::vector<uint16_t> table;
-    if (!sample_xy) {
-        table.resize((size_t)cfg->samples * 2);
-        rr_sample_table(cfg->samples, table.data(), nullptr);
-        sample_xy = table.data();
+    if (!sample_xy) { // the built-in table depends on the sample count only: built once per count, not once per frame
+        if (s->table_samples != cfg->samples) {
+            s->table_cache.resize((size_t)cfg->samples * 2);
+            rr_sample_table(cfg->samples, s->table_cache.data(), nullptr);
+            s->table_samples = cfg->samples;
+        }
+        sample_xy = s->table_cache.data();
     }
     HIP_TRY(s->sample_xy.reserve((size_t)cfg->samples * 4));
     HIP_TRY(hipMemcpyAsync(s->sample_xy.p, sample_xy, (size_t)cfg->samples * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st)); // `table` is a stack-local staging buffer
+    HIP_TRY(hipStreamSynchronize(st)); // the caller's table may be a temporary
 
     // ---- accumulators
     HIP_TRY(s->acc_rgb.reserve((size_t)npix * 24));
@@ -762,10 +821,9 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     // (reserving the worst case 2^(d-1) growth per level, as the first version did, capped batches there).
     const uint32_t R = cfg->max_recursion;
     // Arena memory: a quarter of what is free on the device, at most 64 GB (MI355X has 288 GB of HBM3E),
-    // unless RR_QUEUE_BUDGET_MB says otherwise.  Memory already held by this scene's arena counts as free.
-    const char* env_budget = getenv("RR_QUEUE_BUDGET_MB");
+    // unless rr_tuning::queue_budget_bytes says otherwise.  Memory already held by this scene's arena counts as free.
     uint64_t budget;
-    if (env_budget) budget = (uint64_t)atoll(env_budget) << 20;
+    if (s->tuning.queue_budget_bytes) budget = s->tuning.queue_budget_bytes;
     else {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -788,7 +846,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     // lanes adding to one address otherwise cost more than the walks gain.  Needs whole groups per batch.
     uint32_t G = 1;
     {
-        static const uint32_t forced = getenv("RR_SPP_GROUP") ? (uint32_t)atoi(getenv("RR_SPP_GROUP")) : 0u; // developer knob
+        const uint32_t forced = s->tuning.sample_group; // 0 = automatic
         for (uint32_t g = forced ? forced : 64u; g >= 2; g >>= 1)
             if (g <= 64 && !(g & (g - 1)) && cfg->samples % g == 0 && npix % (RR_WAVE / g) == 0 && (uint64_t)npix * g <= B) { G = g; break; }
         if (forced && G != forced) G = 1;
@@ -810,8 +868,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         for (int k = 0; k < 4; k++) HIP_TRY(s->arena[k].reserve(M * elem[k]));
         s->arena_cap = M;
     }
-    const char* env_chunk = getenv("RR_SHADE_CHUNK");
-    const uint64_t chunk = env_chunk ? std::max<uint64_t>(65536, (uint64_t)atoll(env_chunk)) : (64ull << 20);
+    const uint64_t chunk = s->tuning.shade_chunk_rays ? std::max<uint64_t>(65536, s->tuning.shade_chunk_rays) : (64ull << 20);
     const uint64_t sq_need = std::max<uint64_t>(1, (std::min<uint64_t>(chunk, M) + RR_BLOCK * RR_SQ_SHARDS) * std::max<uint32_t>(s->n_enabled_lights, 1u));
     if (sq_need > s->sq_cap) {
         for (int k = 0; k < 3; k++) HIP_TRY(s->sq[k].reserve(sq_need * 16));
@@ -844,7 +901,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         const DRayQueue qin = queue_at(base);
         {
             uint32_t* head = words(1);
-            if (!head) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise RR_SHADE_CHUNK");
+            if (!head) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise rr_tuning::shade_chunk_rays");
             ScopedTimer t(s, st, 0);
             const int grid = (int)std::min<uint64_t>((n + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)trace_grid);
             hipLaunchKernelGGL(k_trace_closest, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, qin, count, head);
@@ -863,7 +920,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         for (uint64_t s0 = 0; s0 < n; s0 += slice) {
             const uint64_t s1 = std::min<uint64_t>(s0 + slice, n);
             uint32_t* child_count = words(1);
-            if (!child_count) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise RR_SHADE_CHUNK");
+            if (!child_count) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise rr_tuning::shade_chunk_rays");
             const DRayQueue qout = queue_at(child_base);
             for (uint64_t c0 = s0; c0 < s1; c0 += chunk) {
                 if (cancel && *cancel) { (void)hipStreamSynchronize(st); return fail(RR_ERR_CANCELLED, "cancelled"); }
@@ -875,7 +932,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
                 next_word = (next_word + 31u) & ~31u; // the append counters start on a 128-B line
                 uint32_t* sq_counts = words(RR_SQ_SHARDS * RR_SQ_STRIDE);
                 uint32_t* shead = words(1);
-                if (!sq_counts || !shead) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise RR_SHADE_CHUNK");
+                if (!sq_counts || !shead) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise rr_tuning::shade_chunk_rays");
                 {
                     ScopedTimer t(s, st, 2);
                     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, fr, s->region_xy.as<uint32_t>(), qin, count,
@@ -1004,11 +1061,19 @@ extern "C" int rr_scene_last_stats(const rr_scene* cs, rr_frame_stats* out) {
     return RR_OK;
 }
 
-// profiling switch (per-launch HIP events around the trace / shade kernels)
-extern "C" int rr_scene_set_profiling(rr_scene* s, int enabled) {
-    if (!s) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
+extern "C" int rr_scene_set_tuning(rr_scene* s, const rr_tuning* t) {
+    if (!s || !t) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (t->struct_size != sizeof(rr_tuning)) return fail(RR_ERR_INVALID_ARGUMENT, "rr_tuning::struct_size %u, library expects %zu", t->struct_size, sizeof(rr_tuning));
+    if (t->sample_group > 64u || (t->sample_group & (t->sample_group - 1u))) return fail(RR_ERR_INVALID_ARGUMENT, "sample_group %u is not 0 or a power of two <= 64", t->sample_group);
     std::lock_guard<std::mutex> lk(s->mu);
-    s->profiling = enabled != 0;
+    s->tuning = *t;
+    s->profiling = t->kernel_timing != 0;
+    return RR_OK;
+}
+extern "C" int rr_scene_get_tuning(const rr_scene* s, rr_tuning* t) {
+    if (!s || !t) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
+    *t = s->tuning;
+    t->struct_size = (uint32_t)sizeof(rr_tuning);
     return RR_OK;
 }
 

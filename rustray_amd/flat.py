@@ -116,6 +116,11 @@ class rr_frame_stats(C.Structure):
     ]
 
 
+class rr_tuning(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("sample_group", C.c_uint32), ("queue_budget_bytes", C.c_uint64),
+                ("shade_chunk_rays", C.c_uint64), ("kernel_timing", C.c_uint32), ("_pad", C.c_uint32)]
+
+
 # ---------------------------------------------------------------------------
 # numpy-side description
 # ---------------------------------------------------------------------------
@@ -145,6 +150,18 @@ class Material:
                "shadow_softness", "roughness"]
     _BOOLS = ["texture_filtering_nearest", "cast_shadow", "receive_shadow", "monte_carlo",
               "smooth_shading", "reflection_only", "backface_cullig"]
+
+    def c_struct(self) -> "rr_material":
+        c = rr_material()
+        c.ambient_color[:] = [np.float32(v) for v in self.ambient_color]
+        c.base_color[:] = [np.float32(v) for v in self.base_color]
+        c.specular_color[:] = [np.float32(v) for v in self.specular_color]
+        for f in Material._FLOATS:
+            setattr(c, f, np.float32(getattr(self, f)))
+        c.texture[:] = self.texture
+        for b in Material._BOOLS:
+            setattr(c, b, 1 if getattr(self, b) else 0)
+        return c
 
     def to_row(self) -> np.ndarray:
         r = list(self.ambient_color) + list(self.base_color) + list(self.specular_color)
@@ -234,15 +251,7 @@ class FlatScene:
             texs[i].rgba8 = t.ctypes.data
         mats = (rr_material * max(1, len(self.materials)))()
         for i, m in enumerate(self.materials):
-            c = mats[i]
-            c.ambient_color[:] = [np.float32(v) for v in m.ambient_color]
-            c.base_color[:] = [np.float32(v) for v in m.base_color]
-            c.specular_color[:] = [np.float32(v) for v in m.specular_color]
-            for f in Material._FLOATS:
-                setattr(c, f, np.float32(getattr(m, f)))
-            c.texture[:] = m.texture
-            for b in Material._BOOLS:
-                setattr(c, b, 1 if getattr(m, b) else 0)
+            mats[i] = m.c_struct()
         meshes = (rr_mesh * max(1, len(self.meshes)))()
         for i, md in enumerate(self.meshes):
             c = meshes[i]

@@ -36,6 +36,17 @@ def test_struct_sizes_match_header():
     assert C.sizeof(flat.rr_camera) == 8 + 128
     assert C.sizeof(flat.rr_config) == 8 + 6 * 4 + 4 + 4
     assert C.sizeof(flat.rr_region) == 16 and C.sizeof(flat.rr_pick_result) == 16
+    assert C.sizeof(flat.rr_tuning) == 32
+
+
+def test_sample_count_limit():
+    """u16 `(samples + 2).next_power_of_two()` of the reference overflows beyond 32766; the library stops at RR_MAX_SAMPLES."""
+    xy = np.zeros((20000, 2), np.uint16)
+    cs = C.c_uint32(0)
+    assert capi.lib().rr_sample_table(C.c_uint16(16383), xy.ctypes.data_as(C.c_void_p), C.byref(cs)) == -2
+    assert "samples" in capi.lib().rr_last_error().decode()
+    got, cell = capi.sample_table(6)
+    assert cell == 4 and len(got) == 6 and len({(int(a), int(b)) for a, b in got}) == 6
 
 
 def test_region_pixel_count_partitions_the_frame():

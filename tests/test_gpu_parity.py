@@ -126,18 +126,16 @@ def test_explicit_sample_table_equals_builtin(hip):
     assert (a["rgba"] != c["rgba"]).any()
 
 
-def test_batching_and_chunking_do_not_change_a_single_bit(hip, monkeypatch):
+def test_batching_and_chunking_do_not_change_a_single_bit(hip):
     """Fixed-point accumulation: any batch size / shade chunk gives the same bits (depth and normals too)."""
     fs = load_scene("monkey_room")
     cam = camera_for(fs, 96, 54).c_struct()
     cfg = make_config(samples=6, monte_carlo=True, seed=33)
     outs = []
     stats = []
-    for budget, chunk in (("16384", None), ("4", "65536"), ("1", "65536"), ("0", "65536")):
-        monkeypatch.setenv("RR_QUEUE_BUDGET_MB", budget)
-        if chunk:
-            monkeypatch.setenv("RR_SHADE_CHUNK", chunk)
+    for budget_mb, chunk in ((16384, 0), (4, 65536), (1, 65536), (0, 65536)):
         with hip.DeviceScene(fs, 0) as ds:
+            ds.set_tuning(queue_budget_bytes=max(budget_mb << 20, 1), shade_chunk_rays=chunk)  # rr_tuning: 0 would mean automatic
             outs.append(ds.render(cam, cfg))
             stats.append(ds.stats())
     assert stats[0]["batches"] == 1 and stats[-1]["batches"] > 4
@@ -146,7 +144,7 @@ def test_batching_and_chunking_do_not_change_a_single_bit(hip, monkeypatch):
         assert np.array_equal(o["normal"], outs[0]["normal"], equal_nan=True) and (o["object_id"] == outs[0]["object_id"]).all()
 
 
-def test_branching_scene_in_a_small_ray_arena_is_sliced_depth_first(hip, monkeypatch):
+def test_branching_scene_in_a_small_ray_arena_is_sliced_depth_first(hip):
     """Every hit on glass spawns two children; with a ray arena of a few thousand rays the deeper levels do not fit
     behind their parents at once, so levels are shaded in slices whose subtrees finish first (rr_api.hip run_level).
     Same bits as the unconstrained frame."""
@@ -173,9 +171,8 @@ def test_branching_scene_in_a_small_ray_arena_is_sliced_depth_first(hip, monkeyp
             ref = ds.render(cam, cfg)
         st0 = ds.stats()
     assert st_first["sliced_levels"] > 0 and np.array_equal(first["rgba"], ref["rgba"])
-    monkeypatch.setenv("RR_QUEUE_BUDGET_MB", "0")
-    monkeypatch.setenv("RR_SHADE_CHUNK", "65536")
     with hip.DeviceScene(fs, 0) as ds:
+        ds.set_tuning(queue_budget_bytes=1, shade_chunk_rays=65536)
         out = ds.render(cam, cfg)
         st = ds.stats()
     assert st0["sliced_levels"] == 0 and st["sliced_levels"] > 0 and st["batches"] > 1

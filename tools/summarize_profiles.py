@@ -1,4 +1,10 @@
-"""Turns gpurun_out/<tag>/ (made by tools/profile_round.sh on the GPU box) into the committed summaries under profiles/."""
+"""Turns gpurun_out/<tag>/ (made by tools/profile_round.sh on the GPU box) into the committed summaries under profiles/:
+    <name>_bench_sponza_syn_n1.json   the bench line of the run
+    <name>_kernel_stats_sponza_syn.csv   rocprofv3 --kernel-trace --stats
+    <name>_hbm_traffic.json           FETCH_SIZE / WRITE_SIZE per kernel (separate passes, gfx950 correction applied)
+    <name>_sq_counters.json           SQ instruction / wait counters per kernel + the derived issue fractions bench.py quotes
+    <name>_tcp_counters.json          vector-L1 (TCP) and L2 (TCC) counters per kernel
+usage: python tools/summarize_profiles.py <tag> <name>   e.g. r02c r02"""
 import collections
 import csv
 import glob
@@ -7,33 +13,123 @@ import os
 import shutil
 import sys
 
-tag, name = sys.argv[1], sys.argv[2]  # e.g. r01c r01
+tag, name = sys.argv[1], sys.argv[2]
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
-shutil.copy(os.path.join(src, "bench_n1.json"), f"profiles/{name}_bench_sponza_syn_n1.json")
-stats = max(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)  # gpurun merges into older local copies
-shutil.copy(stats, f"profiles/{name}_kernel_stats_sponza_syn.csv")
-data = {}
-for cname, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    f = max(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
-    agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
-        agg[k][0] += 1
-        agg[k][1] += float(r["Counter_Value"])
-    data[cname] = agg
-out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (two separate passes)",
-       "workload": "sponza_syn 1280x720 128spp monte_carlo=1, one frame", "unit": "bytes",
-       "correction": "FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B for 16-B/lane streams, MI355X_MICROARCH.md HBM section); WRITE_SIZE is used as read. "
-                     "Calibration in this access pattern: k_raygen WRITE_SIZE per launch equals rays x 40 B exactly. The ray-queue reads of the trace kernels are 16-B/lane streams "
-                     "(the x2 case); BVH node / triangle gathers mostly hit L2 / Infinity Cache and are uncalibrated.",
-       "kernels": {}}
-for k in ("k_trace_closest", "k_trace_shadow", "k_shade", "k_raygen", "k_resolve"):
-    n = data["FETCH_SIZE"][k][0]
-    fr, wr = data["FETCH_SIZE"][k][1] * 1024, data["WRITE_SIZE"][k][1] * 1024
-    out["kernels"][k] = {"launches_per_frame": n, "FETCH_SIZE_raw_bytes_per_frame": fr, "WRITE_SIZE_bytes_per_frame": wr,
-                         "hbm_bytes_per_launch_corrected": (2 * fr + wr) / max(n, 1)}
-out["k_trace_closest_bytes_per_launch"] = out["kernels"]["k_trace_closest"]["hbm_bytes_per_launch_corrected"]
-json.dump(out, open(f"profiles/{name}_hbm_traffic.json", "w"), indent=1)
-print(json.dumps({k: v["hbm_bytes_per_launch_corrected"] for k, v in out["kernels"].items()}))
-print(open(f"profiles/{name}_kernel_stats_sponza_syn.csv").read()[:900])
+KERNELS = ("k_trace_closest", "k_trace_shadow", "k_shade", "k_raygen", "k_resolve")
+N_SIMD, CLOCK_GHZ = 1024, 2.4
+
+
+def newest(pattern):
+    c = glob.glob(os.path.join(src, pattern), recursive=True)
+    return max(c, key=os.path.getmtime) if c else None  # gpurun merges into older local copies
+
+
+def counters(sub):
+    """{kernel: {counter: [launches, sum]}} of one PMC pass."""
+    f = newest(os.path.join(sub, "**", "*_counter_collection.csv"))
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    if f:
+        for r in csv.DictReader(open(f)):
+            a = agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return agg
+
+
+bench = None
+for cand in ("bench_n1.json", "stats_bench.json"):
+    p = os.path.join(src, cand)
+    if os.path.exists(p) and os.path.getsize(p) > 0:
+        bench = json.loads(open(p).read().strip().splitlines()[-1])
+        if cand == "bench_n1.json":
+            shutil.copy(p, f"profiles/{name}_bench_sponza_syn_n1.json")
+        break
+workload = bench["config"]["workload"] if bench else "?"
+rays_closest = (bench["rays_per_frame"]["primary"] + bench["rays_per_frame"]["secondary"]) if bench else None
+rays_shadow = bench["rays_per_frame"]["shadow"] if bench else None
+
+stats = newest(os.path.join("stats", "**", "*_kernel_stats.csv"))
+kernel_ns = {}
+if stats:
+    shutil.copy(stats, f"profiles/{name}_kernel_stats_sponza_syn.csv")
+    for r in csv.DictReader(open(stats)):
+        kernel_ns[r["Name"].split("(")[0]] = dict(calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), total_ns=float(r["TotalDurationNs"]))
+
+# ---- HBM traffic
+fetch, write = counters("pmc_fetch"), counters("pmc_write")
+if fetch and write:
+    out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras (two separate passes)",
+           "workload": workload + ", one frame", "unit": "bytes",
+           "correction": "FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B for 16-B/lane streams, MI355X_MICROARCH.md HBM section); WRITE_SIZE is used as read. "
+                         "The ray-queue reads of the trace kernels are 16-B/lane streams (the x2 case); BVH node / triangle gathers mostly hit L2 / Infinity Cache and are uncalibrated.",
+           "kernels": {}}
+    for k in KERNELS:
+        if k not in fetch:
+            continue
+        n = fetch[k]["FETCH_SIZE"][0]
+        fr, wr = fetch[k]["FETCH_SIZE"][1] * 1024, write[k]["WRITE_SIZE"][1] * 1024
+        out["kernels"][k] = {"launches_per_frame": n, "FETCH_SIZE_raw_bytes_per_frame": fr, "WRITE_SIZE_bytes_per_frame": wr,
+                             "hbm_bytes_per_launch_corrected": (2 * fr + wr) / max(n, 1)}
+    out["k_trace_closest_bytes_per_launch"] = out["kernels"]["k_trace_closest"]["hbm_bytes_per_launch_corrected"]
+    json.dump(out, open(f"profiles/{name}_hbm_traffic.json", "w"), indent=1)
+
+# ---- SQ counters
+sq = collections.defaultdict(dict)
+for sub in ("pmc_sq1", "pmc_sq2"):
+    for k, d in counters(sub).items():
+        for c, (n, v) in d.items():
+            sq[k][c] = v
+            sq[k]["launches"] = n
+if sq:
+    out = {"command": "rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras (one run per counter set, tools/profile_round.sh)",
+           "workload": workload + ", one frame; counters summed over the launches of the frame",
+           "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_INSTS_* count wave-instructions; SQ_BUSY_CYCLES is summed over the shader engines",
+           "valu_issue_peak": f"{N_SIMD} SIMD-32 x {CLOCK_GHZ} GHz / 2 cycles per wave64 VALU instruction = {N_SIMD * CLOCK_GHZ / 2:.1f} G wave-inst/s",
+           "kernels": {}}
+    for k in KERNELS:
+        if k not in sq:
+            continue
+        d = dict(sq[k])
+        rays = rays_closest if k == "k_trace_closest" else (rays_shadow if k == "k_trace_shadow" else None)
+        if rays and "SQ_INSTS_VALU" in d:
+            d["rays_per_frame"] = rays
+            d["valu_insts_per_ray"] = d["SQ_INSTS_VALU"] / rays
+            d["vmem_insts_per_ray"] = d.get("SQ_INSTS_VMEM", 0.0) / rays
+        if "SQ_WAVE_CYCLES" in d and "SQ_WAIT_ANY" in d:
+            d["wait_any_frac"] = d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"]
+            d["wait_inst_any_frac"] = d.get("SQ_WAIT_INST_ANY", 0.0) / d["SQ_WAVE_CYCLES"]
+            d["active_inst_any_frac"] = d.get("SQ_ACTIVE_INST_ANY", 0.0) / d["SQ_WAVE_CYCLES"]
+        if k in kernel_ns and "SQ_INSTS_VALU" in d:
+            # the stats run renders 4 frames (1 warm-up + 3 timed); the counter runs render one
+            per_frame_ns = kernel_ns[k]["total_ns"] / 4.0
+            d["kernel_ms_per_frame_unprofiled"] = per_frame_ns / 1e6
+            d["valu_issue_frac"] = d["SQ_INSTS_VALU"] / (per_frame_ns * 1e-9) / (N_SIMD * CLOCK_GHZ * 1e9 / 2)
+        if "SQ_THREAD_CYCLES_VALU" in d and "SQ_ACTIVE_INST_VALU" in d and d["SQ_ACTIVE_INST_VALU"]:
+            d["avg_active_lanes_per_valu"] = d["SQ_THREAD_CYCLES_VALU"] / d["SQ_ACTIVE_INST_VALU"]  # of 64
+        out["kernels"][k] = d
+    json.dump(out, open(f"profiles/{name}_sq_counters.json", "w"), indent=1)
+
+# ---- TCP / TCC / GRBM counters
+tc = collections.defaultdict(dict)
+for sub in ("pmc_tcp1", "pmc_tcp2", "pmc_tcc", "pmc_grbm"):
+    for k, d in counters(sub).items():
+        for c, (n, v) in d.items():
+            tc[k][c] = v
+            tc[k]["launches"] = n
+if tc:
+    out = {"command": "rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras (one run per counter set)",
+           "workload": workload + ", one frame", "kernels": {}}
+    for k in KERNELS:
+        if k not in tc:
+            continue
+        d = dict(tc[k])
+        if d.get("TCC_HIT_sum") is not None and d.get("TCC_MISS_sum") is not None and d["TCC_HIT_sum"] + d["TCC_MISS_sum"] > 0:
+            d["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
+        if d.get("TCP_GATE_EN1_sum") and d.get("TCP_PENDING_STALL_CYCLES_sum") is not None:
+            d["tcp_pending_stall_frac"] = d["TCP_PENDING_STALL_CYCLES_sum"] / d["TCP_GATE_EN1_sum"]
+        if d.get("GRBM_GUI_ACTIVE") and k in kernel_ns:
+            d["effective_clock_ghz"] = d["GRBM_GUI_ACTIVE"] / 8.0 / (kernel_ns[k]["total_ns"] / 4.0)
+        out["kernels"][k] = d
+    json.dump(out, open(f"profiles/{name}_tcp_counters.json", "w"), indent=1)
+print("wrote", sorted(glob.glob(f"profiles/{name}_*")))
