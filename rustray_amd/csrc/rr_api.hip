@@ -80,7 +80,7 @@ struct rr_scene {
     int n_cus = 256;
     std::mutex mu;
     // scene data
-    DevBuf items, nodes, nodes4, tnodes4, tris, trix, attrs, face_slot, materials, textures, texels, lights;
+    DevBuf items, nodes4, tnodes4, tris, trix, attrs, face_slot, materials, textures, texels, lights;
     DSceneView view{};
     std::vector<DItem> h_items;
     std::vector<ItemHost> item_host; // what rr_scene_update_materials needs to rebuild the item flag words
@@ -373,12 +373,11 @@ static void world_box(const rr_item& it, float* lo, float* hi) {
     }
 }
 
-static int build_tlas(rr_scene* s, const std::vector<rr_item>& items, std::vector<DNode>* tlas, int32_t* root,
-                      std::vector<DNode4>* tlas4, int32_t* root4) {
+static int build_tlas(rr_scene* s, const std::vector<rr_item>& items, std::vector<DNode4>* tlas4, int32_t* root4) {
     uint32_t n = (uint32_t)items.size();
+    tlas4->clear();
     if (n == 0) { // empty scene: every walk ends at once
-        tlas->clear(); tlas4->clear();
-        *root = *root4 = (int32_t)0x80000000; // RR_SENTINEL
+        *root4 = (int32_t)0x80000000; // RR_SENTINEL
         return RR_OK;
     }
     std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
@@ -394,19 +393,11 @@ static int build_tlas(rr_scene* s, const std::vector<rr_item>& items, std::vecto
             if (c[k] < 0) { uint32_t first = RR_LEAF_FIRST(~c[k]); c[k] = ~(int32_t)r.order[first]; }
         memcpy(&nd.n3.x, &c[0], 4); memcpy(&nd.n3.y, &c[1], 4);
     }
-    *root = r.root;
-    if (r.root < 0) *root = ~(int32_t)r.order[RR_LEAF_FIRST(~r.root)];
+    if (r.root < 0) r.root = ~(int32_t)r.order[RR_LEAF_FIRST(~r.root)];
     // the form the kernels walk: collapsed to 4-wide nodes within the top level's share of the traversal stack
-    {
-        rr::BvhResult r4 = r;
-        r4.root = *root;
-        int pending = 0;
-        tlas4->clear();
-        *root4 = rr::collapse_bvh4(r4, s->tlas_depth_limit, false, tlas4, &pending);
-        if (pending > s->tlas_depth_limit) return fail(RR_ERR_UNSUPPORTED, "top level: BVH4 stack bound exceeded");
-    }
-    *tlas = std::move(r.nodes);
-    (void)s;
+    int pending = 0;
+    *root4 = rr::collapse_bvh4(r, s->tlas_depth_limit, false, tlas4, &pending);
+    if (pending > s->tlas_depth_limit) return fail(RR_ERR_UNSUPPORTED, "top level: BVH4 stack bound exceeded");
     return RR_OK;
 }
 
@@ -472,9 +463,8 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     s->tlas_depth_limit = (int)std::min<uint32_t>(RR_TLAS_MAX_DEPTH, std::max<uint32_t>(1u, fs->n_items > 1 ? fs->n_items - 1 : 1u));
     s->blas_depth_limit = RR_STACK_DEPTH - 3 - s->tlas_depth_limit;
     // ---- meshes: one BLAS per mesh, shared by every item that names it
-    struct MeshDev { uint32_t node_base, tri_base, n_tris; int32_t root; uint32_t node_base4; int32_t root4; bool has_normals; };
+    struct MeshDev { uint32_t tri_base, n_tris; uint32_t node_base4; int32_t root4; bool has_normals; };
     std::vector<MeshDev> md(fs->n_meshes);
-    std::vector<DNode> all_nodes;
     std::vector<DNode4> all_nodes4;
     std::vector<DTri> all_tris;
     std::vector<DTriX> all_trix;
@@ -495,20 +485,15 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         rr::BvhResult r;
         if (!rr::build_bvh(lo.data(), hi.data(), nt, RR_MAX_LEAF_TRIS, s->blas_depth_limit, &r))
             return fail(RR_ERR_UNSUPPORTED, "mesh %u: BVH depth limit exceeded", mi);
-        md[mi].node_base = (uint32_t)all_nodes.size();
         md[mi].tri_base = (uint32_t)all_tris.size();
         md[mi].n_tris = nt;
-        md[mi].root = r.root;
         md[mi].has_normals = m.n_normals > 0 && m.n_normal_faces > 0;
-        all_nodes.insert(all_nodes.end(), r.nodes.begin(), r.nodes.end());
-#if RR_BVH4
-        int pending = 0;
-        md[mi].node_base4 = (uint32_t)all_nodes4.size();
-        md[mi].root4 = rr::collapse_bvh4(r, s->blas_depth_limit, true, &all_nodes4, &pending);
-        if (pending > s->blas_depth_limit) return fail(RR_ERR_UNSUPPORTED, "mesh %u: BVH4 stack bound exceeded", mi);
-#else
-        md[mi].node_base4 = 0; md[mi].root4 = r.root;
-#endif
+        {
+            int pending = 0;
+            md[mi].node_base4 = (uint32_t)all_nodes4.size();
+            md[mi].root4 = rr::collapse_bvh4(r, s->blas_depth_limit, true, &all_nodes4, &pending);
+            if (pending > s->blas_depth_limit) return fail(RR_ERR_UNSUPPORTED, "mesh %u: BVH4 stack bound exceeded", mi);
+        }
         size_t fs_base = all_face_slot.size();
         all_face_slot.resize(fs_base + nt);
         for (uint32_t slot = 0; slot < nt; slot++) {
@@ -522,14 +507,12 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
             t.v1 = make_float4(b[0], b[1], b[2], 0.0f);
             t.v2 = make_float4(c[0], c[1], c[2], 0.0f);
             all_tris.push_back(t);
-            {   // the sequence ray_triangle evaluated per test: ab = b - a, ac = c - a, n = cross3(ab, ac) (rr_math.h)
+            {   // the edge vectors parry's test evaluates per ray: ab = b - a, ac = c - a
                 const float ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
-                const float nx = ab[1] * ac[2] - ab[2] * ac[1], ny = ab[2] * ac[0] - ab[0] * ac[2], nz = ab[0] * ac[1] - ab[1] * ac[0];
                 DTriX x;
                 x.t0 = t.v0;
-                x.t1 = make_float4(ab[0], ab[1], ab[2], nx);
-                x.t2 = make_float4(ac[0], ac[1], ac[2], ny);
-                x.t3 = make_float4(nz, 0.0f, 0.0f, 0.0f);
+                x.t1 = make_float4(ab[0], ab[1], ab[2], ac[0]);
+                x.t2 = make_float4(ac[1], ac[2], 0.0f, 0.0f);
                 all_trix.push_back(x);
             }
             DTriAttr at;
@@ -573,7 +556,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         ih = ItemHost{it.kind, it.material, it.material_cache, it.visible != 0, it.flip_normals != 0, false};
         if (it.kind != RR_ITEM_SPHERE) {
             const MeshDev& m = md[it.mesh];
-            d.node_base = m.node_base; d.root = m.root; d.tri_base = m.tri_base; d.n_tris = m.n_tris;
+            d.tri_base = m.tri_base; d.n_tris = m.n_tris;
             d.node_base4 = m.node_base4; d.root4 = m.root4;
             ih.mesh_has_normals = m.has_normals;
         }
@@ -584,43 +567,39 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     // ---- top level: always present (even for one item), so the kernels have a single traversal path.
     // The reference's choice between "all items" and its scene BVH (src/raytracing.rs:434) only changes the
     // candidate set, never the result.
-    std::vector<DNode> tlas;
     std::vector<DNode4> tlas4;
-    int32_t tlas_root = (int32_t)0x80000000, tlas_root4 = (int32_t)0x80000000; // RR_SENTINEL: empty scene
-    if (fs->n_items >= 1) {
+    int32_t tlas_root4 = (int32_t)0x80000000; // RR_SENTINEL: empty scene
+    {
         std::vector<rr_item> items(fs->items, fs->items + fs->n_items);
-        rc = build_tlas(s.get(), items, &tlas, &tlas_root, &tlas4, &tlas_root4);
+        rc = build_tlas(s.get(), items, &tlas4, &tlas_root4);
         if (rc != RR_OK) return rc;
     }
-    uint32_t tlas_base = (uint32_t)all_nodes.size();
-    s->tlas_node_capacity = std::max<uint32_t>((uint32_t)tlas.size(), fs->n_items ? fs->n_items : 1u);
-    all_nodes.insert(all_nodes.end(), tlas.begin(), tlas.end());
-    all_nodes.resize((size_t)tlas_base + s->tlas_node_capacity); // room for rebuilds after transform updates
+    s->tlas_node_capacity = std::max<uint32_t>((uint32_t)tlas4.size(), fs->n_items ? fs->n_items : 1u); // room for rebuilds after transform updates
 
     auto upload = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
         hipError_t e = b.reserve(std::max<size_t>(bytes, 16));
         if (e != hipSuccess) return e;
         return bytes ? hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
     };
-    HIP_TRY(upload(s->nodes, all_nodes.data(), all_nodes.size() * sizeof(DNode)));
-    if (all_nodes4.size() >= (1u << 25)) return fail(RR_ERR_UNSUPPORTED, "%zu BVH4 nodes (node rows are addressed with 32-bit byte offsets)", all_nodes4.size());
+    if (all_nodes4.size() >= (1u << 25)) return fail(RR_ERR_UNSUPPORTED, "%zu BVH4 nodes (nodes are addressed with 32-bit byte offsets)", all_nodes4.size());
     HIP_TRY(upload(s->nodes4, all_nodes4.data(), all_nodes4.size() * sizeof(DNode4)));
-    tlas4.resize(std::max<size_t>(tlas4.size(), s->tlas_node_capacity)); // room for rebuilds after transform updates
+    tlas4.resize(std::max<size_t>(tlas4.size(), s->tlas_node_capacity));
     HIP_TRY(upload(s->tnodes4, tlas4.data(), tlas4.size() * sizeof(DNode4)));
     HIP_TRY(upload(s->tris, all_tris.data(), all_tris.size() * sizeof(DTri)));
     if (all_trix.size() >= (1u << 26)) return fail(RR_ERR_UNSUPPORTED, "%zu triangles (addressed with 32-bit byte offsets)", all_trix.size());
+    static_assert(sizeof(DTriX) == 48 && sizeof(DNode4) == 128, "layouts the kernels address by byte offset");
     HIP_TRY(upload(s->trix, all_trix.data(), all_trix.size() * sizeof(DTriX)));
     HIP_TRY(upload(s->attrs, all_attrs.data(), all_attrs.size() * sizeof(DTriAttr)));
     HIP_TRY(upload(s->face_slot, all_face_slot.data(), all_face_slot.size() * 4));
     HIP_TRY(upload(s->items, s->h_items.data(), s->h_items.size() * sizeof(DItem)));
 
     DSceneView& v = s->view;
-    v.items = s->items.as<DItem>(); v.nodes = s->nodes.as<DNode>(); v.nodes4 = s->nodes4.as<DNode4>(); v.tris = s->tris.as<DTri>(); v.trix = s->trix.as<DTriX>(); v.attrs = s->attrs.as<DTriAttr>();
+    v.items = s->items.as<DItem>(); v.nodes4 = s->nodes4.as<DNode4>(); v.tris = s->tris.as<DTri>(); v.trix = s->trix.as<DTriX>(); v.attrs = s->attrs.as<DTriAttr>();
     v.face_slot = s->face_slot.as<uint32_t>();
     v.materials = s->materials.as<DMaterial>(); v.textures = s->textures.as<DTexture>(); v.texels = s->texels.as<uint32_t>();
     v.lights = s->lights.as<DLight>();
     v.n_items = fs->n_items; v.n_lights = fs->n_lights;
-    v.tlas_node_base = tlas_base; v.tlas_root = tlas_root; v.tnodes4 = s->tnodes4.as<DNode4>(); v.tlas_root4 = tlas_root4; v.general_w = general_w ? 1u : 0u;
+    v.tnodes4 = s->tnodes4.as<DNode4>(); v.tlas_root4 = tlas_root4; v.general_w = general_w ? 1u : 0u;
 
     HIP_TRY(s->pool.reserve(POOL_WORDS * 4));
     HIP_TRY(s->counters.reserve(RR_CNT_WORDS * 8));
@@ -659,14 +638,13 @@ extern "C" int rr_scene_update_transforms(rr_scene* s, const float* trans, const
     HIP_TRY(hipMemcpy(s->items.p, s->h_items.data(), n * sizeof(DItem), hipMemcpyHostToDevice));
     s->view.general_w = general_w ? 1u : 0u;
     {
-        std::vector<DNode> tlas; std::vector<DNode4> tlas4; int32_t root = 0, root4 = 0;
-        int rc = build_tlas(s, tmp, &tlas, &root, &tlas4, &root4);
+        std::vector<DNode4> tlas4; int32_t root4 = 0;
+        int rc = build_tlas(s, tmp, &tlas4, &root4);
         if (rc != RR_OK) return rc;
-        if (tlas.size() > s->tlas_node_capacity || tlas4.size() > s->tlas_node_capacity)
-            return fail(RR_ERR_DEVICE, "top-level rebuild needs %zu nodes, capacity %u", tlas.size(), s->tlas_node_capacity);
-        if (!tlas.empty()) HIP_TRY(hipMemcpy(s->nodes.as<DNode>() + s->view.tlas_node_base, tlas.data(), tlas.size() * sizeof(DNode), hipMemcpyHostToDevice));
+        if (tlas4.size() > s->tlas_node_capacity)
+            return fail(RR_ERR_DEVICE, "top-level rebuild needs %zu nodes, capacity %u", tlas4.size(), s->tlas_node_capacity);
         if (!tlas4.empty()) HIP_TRY(hipMemcpy(s->tnodes4.p, tlas4.data(), tlas4.size() * sizeof(DNode4), hipMemcpyHostToDevice));
-        s->view.tlas_root = root; s->view.tlas_root4 = root4;
+        s->view.tlas_root4 = root4;
     }
     return RR_OK;
 }

@@ -101,11 +101,9 @@ RR_DEV bool aabb_cast(const float* mins, const float* maxs, const LRay& ray, boo
 // Written with a single exit: every arithmetic result is the same IEEE value as in parry's two branches
 // (v = -ac.e | ac.e, w = ab.e | -ab.e, toi = -t/d | t/d; negation is exact), rejections keep parry's
 // comparison forms so NaNs fall through exactly as they do there; the division runs for accepted hits only.
-RR_DEV bool ray_triangle(f3 a, f3 ab, f3 ac, f3 n, const LRay& ray, float* toi_out, uint32_t* side_out) {
-#ifdef RR_ABLATE_TRI
-    if (a.x != 123.456f) return false; // timing experiment: triangles are fetched but never tested
-#endif
-    // ab = b - a, ac = c - a, n = cross3(ab, ac): computed once per triangle on the host (DTriX)
+RR_DEV bool ray_triangle(f3 a, f3 ab, f3 ac, const LRay& ray, float* toi_out, uint32_t* side_out) {
+    // ab = b - a, ac = c - a: computed once per triangle on the host (DTriX), with the IEEE sequence parry uses per ray
+    const f3 n = cross3(ab, ac);
     const float d = dot3(n, ray.d);
     const f3 ap = ray.o - a;
     const float t = dot3(ap, n);
@@ -152,27 +150,11 @@ RR_DEV bool ray_ball(float radius, const LRay& ray, bool solid, float* toi_out, 
 }
 
 // ---------------------------------------------------------------------------
-// BVH2 traversal.  Per-lane stack in LDS, lane-interleaved (conflict free).
+// BVH4 traversal (DNode4, rr_device.h).  Per-lane stack in LDS, lane-interleaved (conflict free), terminated by a
+// sentinel entry instead of a depth test.
 // ---------------------------------------------------------------------------
 #define STK(sp) s_stack[(sp) * RR_BLOCK + threadIdx.x]
-// One inner-node step.  The far child is written to the stack slot unconditionally and the stack pointer
-// advanced only when both children are hit (the slot above the top is scratch), so the step has a single
-// branch: pop when neither child is hit.  Stacks are terminated by a sentinel entry instead of a depth test.
-#define RR_NODE_STEP(nodes, sr, bound)                                                                        \
-    {                                                                                                          \
-        const DNode nd = (nodes)[cur];                                                                         \
-        float e0, e1;                                                                                          \
-        const bool h0 = slab2(nd.n0.x, nd.n0.y, nd.n0.z, nd.n0.w, nd.n2.x, nd.n2.y, sr, bound, &e0);           \
-        const bool h1 = slab2(nd.n1.x, nd.n1.y, nd.n1.z, nd.n1.w, nd.n2.z, nd.n2.w, sr, bound, &e1);           \
-        const int c0 = __float_as_int(nd.n3.x), c1 = __float_as_int(nd.n3.y);                                  \
-        const bool both = h0 && h1;                                                                            \
-        const bool take1 = both ? (e1 < e0) : h1;                                                              \
-        STK(sp) = take1 ? c0 : c1;                                                                             \
-        sp += both ? 1 : 0;                                                                                    \
-        if (h0 || h1) cur = take1 ? c1 : c0;                                                                   \
-        else { sp--; cur = STK(sp); }                                                                          \
-    }
-#define RR_SENTINEL ((int)0x80000000) // top-level root of an empty scene
+#define RR_SENTINEL ((int)0x80000000) // bottom of every stack; root of an empty tree
 
 // Developer instrumentation (-DRR_EXP_UTIL): active lanes per executed step, by kind.  Never in the shipped build.
 #ifdef RR_EXP_UTIL
@@ -182,31 +164,6 @@ __device__ unsigned long long g_util[32];
 #else
 #define RR_UTIL(slot)
 #endif
-
-#ifndef RR_BVH4
-#define RR_BVH4 1
-#endif
-#ifndef RR_TLAS4
-#define RR_TLAS4 1
-#endif
-// One top-level inner-node step (explicit depth test; an exhausted stack leaves cur = RR_SENTINEL)
-#define RR_TLAS_STEP(bound_expr)                                                                              \
-    {                                                                                                          \
-        RR_UTIL(0) const DNode nd = nodes[cur];                                                                \
-        const float bound = (bound_expr);                                                                      \
-        float e0, e1;                                                                                          \
-        const bool h0 = slab2(nd.n0.x, nd.n0.y, nd.n0.z, nd.n0.w, nd.n2.x, nd.n2.y, sr, bound, &e0);           \
-        const bool h1 = slab2(nd.n1.x, nd.n1.y, nd.n1.z, nd.n1.w, nd.n2.z, nd.n2.w, sr, bound, &e1);           \
-        const int c0 = __float_as_int(nd.n3.x), c1 = __float_as_int(nd.n3.y);                                  \
-        if (h0 && h1) {                                                                                        \
-            const bool swap = e1 < e0;                                                                         \
-            STK(sp) = swap ? c0 : c1; sp++;                                                                    \
-            cur = swap ? c1 : c0;                                                                              \
-        } else if (h0) cur = c0;                                                                               \
-        else if (h1) cur = c1;                                                                                 \
-        else if (sp == 0) cur = RR_SENTINEL;                                                                   \
-        else { sp--; cur = STK(sp); }                                                                          \
-    }
 
 // The traversal's own box test is NOT part of the parity contract (only the exact primitive tests decide
 // hits), so its reciprocal is the hardware approximation.  The subtraction stays in front of the multiply:
@@ -219,22 +176,6 @@ RR_DEV SlabRay make_slab(f3 o, f3 d) {
     return r;
 }
 
-// Conservative slab test against a (builder-padded) box.  The relative slack
-// on both ends widens the box in proportion to its distance from the origin,
-// which is also how the rounding slop of the exact triangle test grows.
-RR_DEV bool slab2(float lox, float hix, float loy, float hiy, float loz, float hiz,
-                  const SlabRay& r, float bound, float* entry) {
-    float ax = (lox - r.o.x) * r.inv.x, bx = (hix - r.o.x) * r.inv.x;
-    float ay = (loy - r.o.y) * r.inv.y, by = (hiy - r.o.y) * r.inv.y;
-    float az = (loz - r.o.z) * r.inv.z, bz = (hiz - r.o.z) * r.inv.z;
-    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), RR_FLT_MAX));
-    float tn_c = tn * 0.999996f;
-    *entry = tn;
-    return tn_c <= tf * 1.000004f && tn_c <= bound;
-}
-
-#if RR_BVH4
 // One BVH4 inner-node step: four slab tests, a five-exchange sorting network on (entry, child), the three
 // farther children written far-to-near with the stack pointer advanced past the ones that were hit (a missed
 // child sorts last and its slot is overwritten), and the nearest taken directly.  Single branch, like the BVH2 step.
@@ -321,22 +262,13 @@ RR_DEV float4 node_row(const DNode4* nodes, uint32_t byte_off) { return *(const 
         if (h0) cur = __float_as_int(cc.x);                                                                    \
         else { sp--; cur = STK(sp); }                                                                          \
     }
-#define RR_BLAS_NODES(sc, it) ((sc).nodes4) // uniform; the tree's base is folded into the row offsets of the Slab4
+#define RR_BLAS_NODES(sc, it) ((sc).nodes4) // uniform; the tree's base is folded into the node offsets of the Slab4
 #define RR_BLAS_ROOT(it) ((it).root4)
 #define RR_BLAS_STEP(nodes, sr, bound) RR_NODE4_STEP(nodes, sr, bound)
 #define RR_BLAS_STEP_ANY(nodes, sr, bound) RR_NODE4_STEP_ANY(nodes, sr, bound)
 #define RR_BLAS_SLAB(r) make_slab4(make_slab((r).o, (r).d), it.node_base4)
 typedef DNode4 BlasNode;
 typedef Slab4 BlasSlab;
-#else
-#define RR_BLAS_NODES(sc, it) ((sc).nodes + (it).node_base)
-#define RR_BLAS_ROOT(it) ((it).root)
-#define RR_BLAS_STEP(nodes, sr, bound) RR_NODE_STEP(nodes, sr, bound)
-#define RR_BLAS_STEP_ANY(nodes, sr, bound) RR_NODE_STEP(nodes, sr, bound)
-#define RR_BLAS_SLAB(r) make_slab((r).o, (r).d)
-typedef DNode BlasNode;
-typedef SlabRay BlasSlab;
-#endif
 
 // Nearest triangle of one mesh (TriMesh::cast_local_ray_and_get_normal,
 // reference src/shape/mesh.rs:67).  Ties at bit-equal toi go to the lowest
@@ -349,9 +281,6 @@ struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool foun
 // order in which triangles are tested is free: the winner is the minimum over (toi, face) and the walk only ever
 // prunes with a bound no smaller than the current best.  (Measured before: node steps ran with ~27 of 64 lanes,
 // triangle tests with 7-15.)
-#ifndef RR_POSTPONE
-#define RR_POSTPONE 1
-#endif
 #ifndef RR_PEND_NUM
 #define RR_PEND_NUM 2
 #define RR_PEND_DEN 3
@@ -363,10 +292,10 @@ struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool foun
         const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);                               \
         for (uint32_t i = 0; i < count; i++) {                                                                 \
             RR_UTIL(3)                                                                                         \
-            const DTriX tr = tri_at(sc.trix, (tri_base_ + first + i) << 6);                                    \
+            const DTriX tr = tri_at(sc.trix, (tri_base_ + first + i) * 48u);                                   \
             float t; uint32_t side;                                                                            \
             if (ray_triangle(mk3(tr.t0.x, tr.t0.y, tr.t0.z), mk3(tr.t1.x, tr.t1.y, tr.t1.z),                   \
-                             mk3(tr.t2.x, tr.t2.y, tr.t2.z), mk3(tr.t1.w, tr.t2.w, tr.t3.x), ray, &t, &side)) { \
+                             mk3(tr.t1.w, tr.t2.x, tr.t2.y), ray, &t, &side)) {                                \
                 const uint32_t face = __float_as_uint(tr.t0.w);                                                \
                 if (!best.found || t < best.t || (t == best.t && face < best.face)) {                          \
                     best.found = true; best.t = t; best.slot = first + i; best.face = face; best.side = side;  \
@@ -380,10 +309,10 @@ struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool foun
         const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);                               \
         for (uint32_t i = 0; i < count; i++) {                                                                 \
             RR_UTIL(3)                                                                                         \
-            const DTriX tr = tri_at(sc.trix, (tri_base_ + first + i) << 6);                                    \
+            const DTriX tr = tri_at(sc.trix, (tri_base_ + first + i) * 48u);                                   \
             float t; uint32_t side;                                                                            \
             if (ray_triangle(mk3(tr.t0.x, tr.t0.y, tr.t0.z), mk3(tr.t1.x, tr.t1.y, tr.t1.z),                   \
-                             mk3(tr.t2.x, tr.t2.y, tr.t2.z), mk3(tr.t1.w, tr.t2.w, tr.t3.x), ray, &t, &side)) { \
+                             mk3(tr.t1.w, tr.t2.x, tr.t2.y), ray, &t, &side)) {                                \
                 any = true;                                                                                    \
                 if (t <= limit) within = true;                                                                 \
             }                                                                                                  \
@@ -400,7 +329,6 @@ RR_DEV void blas_closest(const DSceneView& sc, const DItem& it, const LRay& ray,
     STK(sp) = RR_SENTINEL; sp++;
     int cur = RR_BLAS_ROOT(it);
     RR_UTIL(4)
-#if RR_POSTPONE
     int pend = 0; // parked leaf (leaf codes are negative), 0 = none
     for (;;) {
         if (cur >= 0) {
@@ -416,16 +344,6 @@ RR_DEV void blas_closest(const DSceneView& sc, const DItem& it, const LRay& ray,
             if (pend != 0) { RR_LEAF_CLOSEST(pend) pend = 0; }
         }
     }
-#else
-    while (cur != RR_SENTINEL) {
-        if (cur >= 0) {
-            RR_BLAS_STEP(nodes, sr, fminf(gbound, best.t))
-        } else {
-            RR_LEAF_CLOSEST(cur)
-            sp--; cur = STK(sp);
-        }
-    }
-#endif
     *out = best;
 }
 
@@ -442,7 +360,6 @@ RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, flo
     int cur = RR_BLAS_ROOT(it);
     RR_UTIL(4)
     // until some hit is known every box matters; afterwards only boxes that can still hold a hit within the limit
-#if RR_POSTPONE
     int pend = 0;
     for (;;) {
         if (cur >= 0) {
@@ -462,17 +379,6 @@ RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, flo
             }
         }
     }
-#else
-    while (cur != RR_SENTINEL) {
-        if (cur >= 0) {
-            RR_BLAS_STEP_ANY(nodes, sr, any ? limit : RR_FLT_MAX)
-        } else {
-            RR_LEAF_ANY(cur)
-            if (within) break;
-            sp--; cur = STK(sp);
-        }
-    }
-#endif
     *found_any = any; *found_within = within;
 }
 
@@ -535,9 +441,6 @@ RR_DEV void closest_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t dep
         if (!ray_ball(it.radius, lr, solid, &t, &inside)) return;
         face = 0u;
     } else {
-#ifdef RR_ABLATE_BLAS
-        if (it.radius != 123.456f) return; // timing experiment: per-mesh trees are never entered
-#endif
         if (it.n_tris == 0u) return;
         TriBest tb;
         blas_closest(sc, it, lr, best->found ? best->t : RR_FLT_MAX, s_stack, sp_base, &tb);
@@ -554,7 +457,6 @@ RR_DEV void trace_closest_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, 
     best->found = false; best->t = RR_FLT_MAX; best->item = -1; best->face = 0u; best->key = 0.0f;
     // top level: world-space boxes over items (stands in for Scene::get_possible_hits_by_ray,
     // reference src/scene.rs:1715-1722; any conservative candidate set gives the same result)
-#if RR_TLAS4
     // the top level in the 4-wide form of the per-mesh trees, same step (sentinel-terminated stack)
     const Slab4 ws = make_slab4(make_slab(o, d), 0u);
     int sp = 1;
@@ -568,22 +470,6 @@ RR_DEV void trace_closest_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, 
         closest_item(sc, (int)RR_LEAF_FIRST((uint32_t)~cur), o, d, depth, s_stack, sp, best); // one item per top-level leaf
         sp--; cur = STK(sp);
     }
-#else
-    const SlabRay sr = make_slab(o, d);
-    const DNode* nodes = sc.nodes + sc.tlas_node_base;
-    int sp = 0;
-    int cur = sc.tlas_root;
-    if (cur == RR_SENTINEL) return; // empty scene
-    for (;;) {
-        while (cur >= 0) { RR_TLAS_STEP(best->t) }
-        if (cur == RR_SENTINEL) break;
-        uint32_t code = (uint32_t)~cur;
-        uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
-        for (uint32_t i = 0; i < count; i++) closest_item(sc, (int)(first + i), o, d, depth, s_stack, sp, best);
-        if (sp == 0) break;
-        sp--; cur = STK(sp);
-    }
-#endif
 }
 
 // Shadow rays stop at the first ITEM (in bbox-distance order) that is hit at all
@@ -643,7 +529,6 @@ RR_DEV bool shadow_blocker_item(const DSceneView& sc, int idx, f3 o, f3 d, uint3
 
 RR_DEV bool trace_shadow_blockers(const DSceneView& sc, f3 o, f3 d, uint32_t depth, float limit, const ShadowSel& sel, int* s_stack) {
     const float bound = sel.key * 1.00001f + 1e-6f; // a blocker's box starts before the occluder's key
-#if RR_TLAS4
     const Slab4 ws = make_slab4(make_slab(o, d), 0u);
     int sp = 1;
     STK(0) = RR_SENTINEL;
@@ -654,22 +539,6 @@ RR_DEV bool trace_shadow_blockers(const DSceneView& sc, f3 o, f3 d, uint32_t dep
         if (shadow_blocker_item(sc, (int)RR_LEAF_FIRST((uint32_t)~cur), o, d, depth, limit, sel, s_stack, sp)) return true;
         sp--; cur = STK(sp);
     }
-#else
-    const SlabRay sr = make_slab(o, d);
-    const DNode* nodes = sc.nodes + sc.tlas_node_base;
-    int sp = 0;
-    int cur = sc.tlas_root;
-    for (;;) {
-        while (cur >= 0) { RR_TLAS_STEP(bound) }
-        if (cur == RR_SENTINEL) break;
-        uint32_t code = (uint32_t)~cur;
-        uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
-        for (uint32_t i = 0; i < count; i++)
-            if (shadow_blocker_item(sc, (int)(first + i), o, d, depth, limit, sel, s_stack, sp)) return true;
-        if (sp == 0) break;
-        sp--; cur = STK(sp);
-    }
-#endif
     return false;
 }
 
@@ -677,7 +546,6 @@ RR_DEV void trace_shadow_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, f
     sel->found = false; sel->within = false; sel->key = 0.0f; sel->item = -1; sel->t = 0.0f; sel->face = 0u;
     // an item whose world box starts beyond the light, or beyond the selected item's key, cannot matter
 #define RR_SHADOW_BOUND (sel->found ? fminf(limit, sel->key * 1.00001f + 1e-6f) : limit)
-#if RR_TLAS4
     const Slab4 ws = make_slab4(make_slab(o, d), 0u);
     int sp = 1;
     STK(0) = RR_SENTINEL;
@@ -688,22 +556,6 @@ RR_DEV void trace_shadow_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, f
         shadow_item(sc, (int)RR_LEAF_FIRST((uint32_t)~cur), o, d, depth, limit, s_stack, sp, sel);
         sp--; cur = STK(sp);
     }
-#else
-    const SlabRay sr = make_slab(o, d);
-    const DNode* nodes = sc.nodes + sc.tlas_node_base;
-    int sp = 0;
-    int cur = sc.tlas_root;
-    if (cur == RR_SENTINEL) return; // empty scene
-    for (;;) {
-        while (cur >= 0) { RR_TLAS_STEP(RR_SHADOW_BOUND) }
-        if (cur == RR_SENTINEL) break;
-        uint32_t code = (uint32_t)~cur;
-        uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);
-        for (uint32_t i = 0; i < count; i++) shadow_item(sc, (int)(first + i), o, d, depth, limit, s_stack, sp, sel);
-        if (sp == 0) break;
-        sp--; cur = STK(sp);
-    }
-#endif
     // The occluder found has a hit within the light distance.  Only if its sort key lies beyond the light (its box
     // contains the ray origin, so the key is the box EXIT distance) can an item that starts beyond the light precede it.
     if (sel->found && sel->within && sel->key > limit && trace_shadow_blockers(sc, o, d, depth, limit, *sel, s_stack)) sel->within = false;
@@ -867,33 +719,50 @@ RR_DEV long long to_fix(float v, float scale, float clampv) {
 // pix = 0xffffffff.  (64 lanes adding to one address, or 16, serialise in the L2 atomic units: +10 ms on sponza_syn.)
 #define RR_DPP_SHR(x, n) __builtin_amdgcn_update_dpp(0, (int)(x), 0x110 + (n), 0xf, 0xf, true)
 #define RR_DPP_SHL(x, n) __builtin_amdgcn_update_dpp(0, (int)(x), 0x100 + (n), 0xf, 0xf, true)
+#define RR_DPP_SHR64(x, n) (((unsigned long long)(uint32_t)RR_DPP_SHR((uint32_t)((x) >> 32), n) << 32) | (uint32_t)RR_DPP_SHR((uint32_t)(x), n))
 #define RR_SEG_STEP(n)                                                                                         \
     {                                                                                                          \
         const int pf = RR_DPP_SHR(f, n);                                                                       \
-        const unsigned long long pr = ((unsigned long long)(uint32_t)RR_DPP_SHR((uint32_t)(vr >> 32), n) << 32) | (uint32_t)RR_DPP_SHR((uint32_t)vr, n); \
-        const unsigned long long pg = ((unsigned long long)(uint32_t)RR_DPP_SHR((uint32_t)(vg >> 32), n) << 32) | (uint32_t)RR_DPP_SHR((uint32_t)vg, n); \
-        const unsigned long long pb = ((unsigned long long)(uint32_t)RR_DPP_SHR((uint32_t)(vb >> 32), n) << 32) | (uint32_t)RR_DPP_SHR((uint32_t)vb, n); \
-        if (!f) { vr += pr; vg += pg; vb += pb; f = pf; }                                                      \
+        _Pragma("unroll") for (int k_ = 0; k_ < N; k_++) { const unsigned long long p_ = RR_DPP_SHR64(v[k_], n); if (!f) v[k_] += p_; } \
+        if (!f) f = pf;                                                                                        \
     }
+// Segmented sum over runs of equal `pix` inside the 16-lane DPP rows: afterwards the LAST lane of every run (return
+// value true) holds the run's sums in v[0..N).  Must be called by all 64 lanes; lanes with nothing to add pass 0xffffffff.
+template <int N> RR_DEV bool wave_merge_runs(uint32_t pix, unsigned long long (&v)[N]) {
+    const uint32_t lane16 = threadIdx.x & 15u;
+    const uint32_t prev = (uint32_t)RR_DPP_SHR(pix, 1);
+    const int head = (lane16 == 0u || prev != pix) ? 1 : 0; // first lane of a run of equal pixels inside its row
+    int f = head;
+    RR_SEG_STEP(1) RR_SEG_STEP(2) RR_SEG_STEP(4) RR_SEG_STEP(8)
+    const int next_head = RR_DPP_SHL(head, 1);
+    return (lane16 == 15u || next_head != 0) && pix != 0xffffffffu;
+}
 RR_DEV void accum_merged(const DAccum& acc, uint32_t pix, long long r, long long g, long long b) {
 #ifdef RR_EXP_NO_ATOMICS
     if (r == 123456789ll) acc.rgb[pix] = 0; // timing experiment only
     return;
 #endif
-    const uint32_t lane16 = threadIdx.x & 15u;
-    const uint32_t prev = (uint32_t)RR_DPP_SHR(pix, 1);
-    const int head = (lane16 == 0u || prev != pix) ? 1 : 0; // first lane of a run of equal pixels inside its row
-    int f = head;
-    unsigned long long vr = (unsigned long long)r, vg = (unsigned long long)g, vb = (unsigned long long)b;
-    RR_SEG_STEP(1) RR_SEG_STEP(2) RR_SEG_STEP(4) RR_SEG_STEP(8)
-    const int next_head = RR_DPP_SHL(head, 1);
-    const bool tail = lane16 == 15u || next_head != 0;
-    if (tail && pix != 0xffffffffu) {
-        // one plane per channel
-        unsigned long long* p = (unsigned long long*)acc.rgb + pix;
-        if (vr) atomicAdd(p, vr);
-        if (vg) atomicAdd(p + acc.n, vg);
-        if (vb) atomicAdd(p + 2ull * acc.n, vb);
+    unsigned long long v[3] = {(unsigned long long)r, (unsigned long long)g, (unsigned long long)b};
+    if (wave_merge_runs<3>(pix, v)) {
+        unsigned long long* p = (unsigned long long*)acc.rgb + pix; // one plane per channel
+        if (v[0]) atomicAdd(p, v[0]);
+        if (v[1]) atomicAdd(p + acc.n, v[1]);
+        if (v[2]) atomicAdd(p + 2ull * acc.n, v[2]);
+    }
+}
+// The aux outputs of the root hits (normal and depth sums, reference src/raytracing.rs:400-402), merged the same way:
+// the samples of a pixel sit in neighbouring lanes, and 64 lanes adding to one address serialise in the L2 atomic
+// units (measured: k_shade 6.5 -> 42.8 ms on sponza_syn when the four aux adds of every primary hit went out unmerged).
+RR_DEV void accum_aux_merged(const DAccum& acc, uint32_t pix, long long nx, long long ny, long long nz, long long depth) {
+    unsigned long long v[4] = {(unsigned long long)nx, (unsigned long long)ny, (unsigned long long)nz, (unsigned long long)depth};
+    if (wave_merge_runs<4>(pix, v)) {
+        if (acc.normal) {
+            unsigned long long* np = (unsigned long long*)acc.normal + pix;
+            if (v[0]) atomicAdd(np, v[0]);
+            if (v[1]) atomicAdd(np + acc.n, v[1]);
+            if (v[2]) atomicAdd(np + 2ull * acc.n, v[2]);
+        }
+        if (acc.depth && v[3]) atomicAdd((unsigned long long*)acc.depth + pix, v[3]);
     }
 }
 
@@ -1097,7 +966,8 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         bool spawn_refl = false, spawn_refr = false;
         float4 c1_r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1_r1 = c1_r0, c2_r0 = c1_r0, c2_r1 = c1_r0;
         uint2 c1_r2 = make_uint2(0u, 0u), c2_r2 = c1_r2;
-        uint32_t sum_pix = 0xffffffffu;
+        uint32_t sum_pix = 0xffffffffu, aux_pix = 0xffffffffu;
+        long long aux_nx = 0, aux_ny = 0, aux_nz = 0, aux_d = 0;
         if (active) {
         n_shaded++;
         const float4 r0 = qin.r0[i], r1 = qin.r1[i];
@@ -1147,15 +1017,11 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
             }
             if (it_flags & RR_IF_FLIP_NORMALS) normal = -normal;
         }
-        // ---- aux outputs of the root node (:742-744, :400-402)
+        // ---- aux outputs of the root node (:742-744, :400-402): summed per pixel below, with the wave's other root hits
         if (depth == 1u) {
-            if (acc.depth) atomicAdd((unsigned long long*)(acc.depth + pix), (unsigned long long)to_fix(hit_dist, RR_DEPTH_SCALE, 1.0e9f));
-            if (acc.normal) {
-                unsigned long long* np = (unsigned long long*)acc.normal + pix;
-                atomicAdd(np, (unsigned long long)to_fix(normal.x, RR_FIX_SCALE, RR_FIX_CLAMP));
-                atomicAdd(np + acc.n, (unsigned long long)to_fix(normal.y, RR_FIX_SCALE, RR_FIX_CLAMP));
-                atomicAdd(np + 2ull * acc.n, (unsigned long long)to_fix(normal.z, RR_FIX_SCALE, RR_FIX_CLAMP));
-            }
+            aux_pix = pix;
+            aux_d = to_fix(hit_dist, RR_DEPTH_SCALE, 1.0e9f);
+            aux_nx = to_fix(normal.x, RR_FIX_SCALE, RR_FIX_CLAMP); aux_ny = to_fix(normal.y, RR_FIX_SCALE, RR_FIX_CLAMP); aux_nz = to_fix(normal.z, RR_FIX_SCALE, RR_FIX_CLAMP);
         }
         // ---- uv (:749-754)
         bool has_uv = false; f2 uv; uv.x = 0.0f; uv.y = 0.0f;
@@ -1321,6 +1187,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         }
         } // active
         accum_merged(acc, sum_pix, sum_r, sum_g, sum_b);
+        if ((acc.normal || acc.depth) && __ballot(aux_pix != 0xffffffffu) != 0ull) accum_aux_merged(acc, aux_pix, aux_nx, aux_ny, aux_nz, aux_d);
         {
             // one allocation for all children of the workgroup iteration: per wave the reflection rays first, then the refraction rays
             const unsigned long long m_refl = __ballot(spawn_refl), m_refr = __ballot(spawn_refr);
