@@ -90,9 +90,10 @@ struct rr_scene {
     uint32_t tlas_node_capacity = 0;
     int tlas_depth_limit = RR_TLAS_MAX_DEPTH, blas_depth_limit = RR_BLAS_MAX_DEPTH; // shares of the traversal stack, see rr_scene_create
     // frame state (grown on demand, reused across frames)
-    DevBuf arena[4];  // ray records of all live depth levels, SoA: r0 r1 r2 hit
+    DevBuf hit1;      // hit records of depth level 1 (the primary rays are derived from their index, not stored)
+    DevBuf arena[4];  // ray records of the deeper live depth levels, SoA: r0 r1 r2 hit
     size_t arena_cap = 0; // rays
-    uint32_t arena_factor = 3; // arena rays per primary ray of a batch; doubled after a frame that had to slice levels
+    uint32_t arena_factor = 2; // arena rays per primary ray of a batch; doubled after a frame that had to slice levels
     DevBuf sq[3];
     size_t sq_cap = 0;
     DevBuf acc_rgb, acc_normal, acc_depth, acc_id;
@@ -805,14 +806,16 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     else {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        budget = std::min<uint64_t>((free_b + 56ull * s->arena_cap) / 4, 64ull << 30);
+        budget = std::min<uint64_t>((free_b + 56ull * s->arena_cap + s->hit1.bytes) / 4, 64ull << 30);
     }
     const uint64_t total_primary = (uint64_t)npix * cfg->samples;
     const uint64_t LEVEL_MAX = 0x7fffff00ull; // ray indices are 32-bit
-    // a batch of B primary rays gets an arena of 3 B: enough for every level of a typical frame at once
-    // (sponza_syn: all deeper levels together hold 4 % of the primaries), sliced when a scene branches more
-    uint64_t B = std::max<uint64_t>(budget / 56ull / 3ull, 4096);
-    B = std::min<uint64_t>(B, std::min<uint64_t>(total_primary, LEVEL_MAX / 3));
+    // Level 1 (the primary rays) needs only its 16-B hit records: the rays themselves are derived from their index
+    // (primary_ray).  The arena holds the deeper levels; 2 arena rays per primary ray cover every level of a typical
+    // frame at once (sponza_syn: all deeper levels together hold 4 % of the primaries), sliced when a scene branches more.
+    const uint64_t per_primary = 16ull + 2ull * 56ull;
+    uint64_t B = std::max<uint64_t>(budget / per_primary, 4096);
+    B = std::min<uint64_t>(B, std::min<uint64_t>(total_primary, LEVEL_MAX));
     if (hook && hook->min_passes > 1) B = std::min<uint64_t>(B, std::max<uint64_t>(npix, (total_primary + hook->min_passes - 1) / hook->min_passes));
     // equal batches (a frame that needs 1.2 batches would otherwise end with a small, poorly filled one)
     { const uint64_t nb = (total_primary + B - 1) / B; B = (total_primary + nb - 1) / nb; }
@@ -836,16 +839,18 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         B = ((total_units + nb - 1) / nb) * unit;
     }
     B = std::min<uint64_t>(B, total_primary);
-    // arena: 3 rays per primary ray, or 8 where that stays under 16 GB (a branching scene then fits on its first frame
-    // too), or `arena_factor` after a frame that had to slice -- always within the budget
-    const uint64_t roomy = std::min<uint64_t>(8 * B, (16ull << 30) / 56ull);
-    const uint64_t want = std::max<uint64_t>(std::max<uint64_t>(3 * B, roomy), (uint64_t)s->arena_factor * B);
-    const uint64_t M = std::min<uint64_t>(std::min<uint64_t>(want, std::max<uint64_t>(3 * B, budget / 56ull)) + 2ull * RR_BLOCK * (R + 1), LEVEL_MAX);
+    // arena (levels 2 and deeper): 2 rays per primary ray, or 7 where that stays under 16 GB (a branching scene then fits
+    // on its first frame too), or `arena_factor` after a frame that had to slice -- always within the budget
+    const uint64_t after_hits = budget > 16ull * B ? (budget - 16ull * B) / 56ull : 0ull;
+    const uint64_t roomy = std::min<uint64_t>(7 * B, (16ull << 30) / 56ull);
+    const uint64_t want = std::max<uint64_t>(std::max<uint64_t>(2 * B, roomy), (uint64_t)s->arena_factor * B);
+    const uint64_t M = std::min<uint64_t>(std::min<uint64_t>(want, std::max<uint64_t>(2 * B, after_hits)) + 2ull * RR_BLOCK * (R + 1), LEVEL_MAX);
     const size_t elem[4] = {16, 16, 8, 16};
     if (M > s->arena_cap) {
         for (int k = 0; k < 4; k++) HIP_TRY(s->arena[k].reserve(M * elem[k]));
         s->arena_cap = M;
     }
+    HIP_TRY(s->hit1.reserve(B * 16));
     const uint64_t chunk = s->tuning.shade_chunk_rays ? std::max<uint64_t>(65536, s->tuning.shade_chunk_rays) : (64ull << 20);
     const uint64_t sq_need = std::max<uint64_t>(1, (std::min<uint64_t>(chunk, M) + RR_BLOCK * RR_SQ_SHARDS) * std::max<uint32_t>(s->n_enabled_lights, 1u));
     if (sq_need > s->sq_cap) {
@@ -874,18 +879,22 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     // One depth level: rays [base, base + n) of the arena, their count also in the device word `count`.
     // The size of the next level is read back once per slice (4 bytes + stream sync), so launches are sized by the
     // rays that exist and empty levels are never launched.
-    std::function<int(uint32_t, uint64_t, uint64_t, const uint32_t*)> run_level =
-        [&](uint32_t d, uint64_t base, uint64_t n, const uint32_t* count) -> int {
-        const DRayQueue qin = queue_at(base);
+    // depth level 1 = the batch's primary rays [pr.first, pr.first + pr.n): only hit records (hit1); its children start the arena
+    DPrimary pr{s->sample_xy.as<uint16_t>(), 0ull, 0u, 1u};
+    std::function<int(uint32_t, uint64_t, uint64_t, uint32_t*)> run_level =
+        [&](uint32_t d, uint64_t base, uint64_t n, uint32_t* count) -> int {
+        DRayQueue qin = queue_at(base);
+        if (d == 1) { qin.r0 = nullptr; qin.r1 = nullptr; qin.r2 = nullptr; qin.hit = s->hit1.as<uint4>(); }
         {
             uint32_t* head = words(1);
             if (!head) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise rr_tuning::shade_chunk_rays");
             ScopedTimer t(s, st, 0);
             const int grid = (int)std::min<uint64_t>((n + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)trace_grid);
-            hipLaunchKernelGGL(k_trace_closest, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, qin, count, head);
+            if (d == 1) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, qin, count, head, fr, s->region_xy.as<uint32_t>(), pr, counters);
+            else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, qin, count, head, fr, s->region_xy.as<uint32_t>(), pr, counters);
         }
         const bool spawns = d <= R; // the deepest level spawns nothing (k_shade: depth <= max_recursion)
-        const uint64_t child_base = base + n;
+        const uint64_t child_base = d == 1 ? 0 : base + n;
         // Children of a slice may use the space behind this level minus what the deeper levels need to make progress
         // themselves (one 256-ray slice = 512 children per spawning level below): the recursion can then never get stuck.
         uint64_t slice = n;
@@ -913,8 +922,10 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
                 if (!sq_counts || !shead) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise rr_tuning::shade_chunk_rays");
                 {
                     ScopedTimer t(s, st, 2);
-                    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, fr, s->region_xy.as<uint32_t>(), qin, count,
-                                       (uint32_t)c0, (uint32_t)c1, qout, child_count, SQ, sq_counts, segcap, acc, counters);
+                    if (d == 1) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, fr, s->region_xy.as<uint32_t>(), pr, qin, count,
+                                                   (uint32_t)c0, (uint32_t)c1, qout, child_count, SQ, sq_counts, segcap, acc, counters);
+                    else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, fr, s->region_xy.as<uint32_t>(), pr, qin, count,
+                                            (uint32_t)c0, (uint32_t)c1, qout, child_count, SQ, sq_counts, segcap, acc, counters);
                 }
                 // The size of the next level is final once the slice's last shade chunk has run: its read-back is enqueued
                 // BEFORE that chunk's shadow kernel, so the host learns it (and enqueues the next level) while the shadow
@@ -947,8 +958,8 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         next_word = 0;
         uint32_t* level1_count = words(1);
         // The batch covers primary indices [first, first + n_batch): index i -> sample i / npix, pixel i % npix.
-        hipLaunchKernelGGL(k_raygen, dim3((n_batch + RR_BLOCK - 1) / RR_BLOCK), dim3(RR_BLOCK), 0, st, fr, s->region_xy.as<uint32_t>(),
-                           s->sample_xy.as<uint16_t>(), (unsigned long long)first, n_batch, (n_batch % ((uint64_t)npix * G) == 0 && first % npix == 0) ? G : 1u, queue_at(0), level1_count, counters);
+        pr.first = first; pr.n = n_batch;
+        pr.group = (n_batch % ((uint64_t)npix * G) == 0 && first % npix == 0) ? G : 1u;
         s->stats.batches++;
         const int rcl = run_level(1, 0, n_batch, level1_count);
         if (rcl != RR_OK) return rcl;
@@ -1150,15 +1161,15 @@ extern "C" int rr_pick(rr_scene* s, const rr_camera* cam, int x, int y, rr_pick_
     fr.width = cam->width; fr.height = cam->height; fr.samples = 1; fr.cell_size = 1; fr.n_region_pixels = 1;
     DevBuf scratch;
     HIP_TRY(scratch.reserve(256));
-    // layout: [0] region_xy, [4] sample_xy (2 x u16), [8] trace_order (= 0), [16] r0, [32] r1, [48] r2, [64] hit, [96] count, [100] head, [128] counters
+    // layout: [0] region_xy, [4] sample_xy (2 x u16), [64] hit, [96] count, [100] head, [128] counters
     char* b = scratch.as<char>();
     uint32_t h_xy = (uint32_t)x | ((uint32_t)y << 16);
     HIP_TRY(hipMemset(b, 0, 256));
     HIP_TRY(hipMemcpy(b, &h_xy, 4, hipMemcpyHostToDevice));
-    DRayQueue q{(float4*)(b + 16), (float4*)(b + 32), (uint2*)(b + 48), (uint4*)(b + 64)};
-    hipLaunchKernelGGL(k_raygen, dim3(1), dim3(RR_BLOCK), 0, nullptr, fr, (const uint32_t*)b, (const uint16_t*)(b + 4), 0ull, 1u, 1u, q,
-                       (uint32_t*)(b + 96), (unsigned long long*)(b + 128));
-    hipLaunchKernelGGL(k_trace_closest, dim3(1), dim3(RR_BLOCK), 0, nullptr, s->view, q, (const uint32_t*)(b + 96), (uint32_t*)(b + 100));
+    DRayQueue q{nullptr, nullptr, nullptr, (uint4*)(b + 64)};
+    DPrimary pr{(const uint16_t*)(b + 4), 0ull, 1u, 1u};
+    hipLaunchKernelGGL(k_trace_closest<true>, dim3(1), dim3(RR_BLOCK), 0, nullptr, s->view, q, (uint32_t*)(b + 96), (uint32_t*)(b + 100), fr,
+                       (const uint32_t*)b, pr, (unsigned long long*)(b + 128));
     uint32_t hit[4];
     HIP_TRY(hipMemcpy(hit, b + 64, 16, hipMemcpyDeviceToHost));
     scratch.release();

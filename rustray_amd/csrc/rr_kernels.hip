@@ -773,7 +773,7 @@ RR_DEV void accum_aux_merged(const DAccum& acc, uint32_t pix, long long nx, long
 #endif
 
 // ---------------------------------------------------------------------------
-// kernel 1: primary rays (reference src/raytracing.rs:319-396)
+// primary rays (reference src/raytracing.rs:319-396)
 // ---------------------------------------------------------------------------
 RR_DEV float4 mat4_mul(const float* m, float x, float y, float z, float w) {
     return make_float4(((m[0] * x + m[4] * y) + m[8] * z) + m[12] * w,
@@ -782,13 +782,21 @@ RR_DEV float4 mat4_mul(const float* m, float x, float y, float z, float w) {
                        ((m[3] * x + m[7] * y) + m[11] * z) + m[15] * w);
 }
 
-__global__ __launch_bounds__(RR_BLOCK) void k_raygen(DFrame fr, const uint32_t* __restrict__ slot_xy,
-                                                     const uint16_t* __restrict__ sample_xy,
-                                                     unsigned long long first, uint32_t n_rays, uint32_t group, DRayQueue q,
-                                                     uint32_t* q_count, unsigned long long* counters) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { *q_count = n_rays; atomicAdd(&counters[RR_CNT_PRIMARY], (unsigned long long)n_rays); }
-    if (i >= n_rays) return;
+// Primary rays are a pure function of (pixel slot, sample): the level-1 trace and shade kernels both DERIVE them
+// instead of reading ray records that a ray-generation kernel wrote (round 1: k_raygen wrote 40 B per primary ray,
+// 4.7 GB per sponza_syn frame, that the trace kernel read straight back and the shade kernel read a third time).
+// Both kernels run the same instruction sequence on the same inputs, so they see the same ray, bit for bit.
+struct DPrimary {
+    const uint16_t* sample_xy;   // the sub-sample table, samples x (x_i, y_i)
+    unsigned long long first;    // first primary index of the batch (sample-major over the region: sample = index / n_pix)
+    uint32_t n;                  // primary rays in the batch
+    uint32_t group;              // samples of one pixel per 64-ray packet (1 = one sample of 64 pixels)
+};
+RR_DEV void primary_ray(const DFrame& fr, const uint32_t* __restrict__ slot_xy, const DPrimary& pr, uint32_t i,
+                        f3* origin_out, f3* dir_out, uint32_t* pix_out, uint32_t* sample_out) {
+    const uint16_t* __restrict__ sample_xy = pr.sample_xy;
+    const unsigned long long first = pr.first;
+    const uint32_t group = pr.group;
     uint32_t pix, s; // accumulator slot (slots enumerate 8x8 blocks of the region's tiles) and sample
     if (group <= 1u) {
         const unsigned long long gi = first + i; // sample-major index over the region: sample = gi / n_pix
@@ -844,18 +852,24 @@ __global__ __launch_bounds__(RR_BLOCK) void k_raygen(DFrame fr, const uint32_t* 
         dir = mk3(d.x, d.y, d.z);
     }
     dir = normalize3(dir); // get_color_depth_normal_id normalises on entry (:723)
-    q.r0[i] = make_float4(origin.x, origin.y, origin.z, 1.0f);
-    q.r1[i] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(pix));
-    q.r2[i] = make_uint2(s | (1u << 16) | (1u << 24), 1u);
+    *origin_out = origin; *dir_out = dir; *pix_out = pix; *sample_out = s;
 }
 
 // ---------------------------------------------------------------------------
 // kernel 2: closest hit for a queue of rays
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_closest(DSceneView sc, DRayQueue q, const uint32_t* __restrict__ q_count,
-                                                            uint32_t* head) {
+// PRIMARY: depth level 1.  The rays are derived from their index (primary_ray), only the 16-B hit record is written;
+// block 0 publishes the level's size for the shade kernel and counts the rays.
+template <bool PRIMARY>
+__global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_closest(DSceneView sc, DRayQueue q, uint32_t* __restrict__ q_count,
+                                                            uint32_t* head, DFrame fr, const uint32_t* __restrict__ slot_xy, DPrimary pr,
+                                                            unsigned long long* counters) {
     __shared__ int s_stack[RR_STACK_DEPTH * RR_BLOCK];
-    const uint32_t n = *q_count;
+    uint32_t n;
+    if (PRIMARY) {
+        n = pr.n;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { *q_count = n; atomicAdd(&counters[RR_CNT_PRIMARY], (unsigned long long)n); }
+    } else n = *q_count;
     const uint32_t lane = threadIdx.x & (RR_WAVE - 1);
     // Work distribution.  Locality decides here: the waves that run side by side must walk neighbouring
     // packets (runs of consecutive packets per wave cost 1.8x, measured), and one head word sustains only ~90
@@ -890,10 +904,15 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_closest(DSce
         if (pkt >= n_packets) break; // wave-uniform
         const uint32_t i = pkt * RR_WAVE + lane;
         if (i < n) {
-            float4 r0 = q.r0[i], r1 = q.r1[i];
-            uint32_t depth = (q.r2[i].x >> 16) & 0xffu;
+            f3 ro, rd; uint32_t depth;
+            if (PRIMARY) { uint32_t pix_, smp_; primary_ray(fr, slot_xy, pr, i, &ro, &rd, &pix_, &smp_); depth = 1u; }
+            else {
+                const float4 r0 = q.r0[i], r1 = q.r1[i];
+                ro = mk3(r0.x, r0.y, r0.z); rd = mk3(r1.x, r1.y, r1.z);
+                depth = (q.r2[i].x >> 16) & 0xffu;
+            }
             Closest best;
-            trace_closest_ray(sc, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), depth, s_stack, &best);
+            trace_closest_ray(sc, ro, rd, depth, s_stack, &best);
             q.hit[i] = make_uint4(__float_as_uint(best.t), (uint32_t)(best.found ? best.item : -1), best.face, 0u);
         }
     }
@@ -927,7 +946,8 @@ RR_DEV float4 item_color(const DSceneView& sc, const MatR& m, bool has_uv, f2 uv
 #ifndef RR_SHADE_WAVES
 #define RR_SHADE_WAVES 4
 #endif
-__global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView sc, DFrame fr, const uint32_t* __restrict__ slot_xy,
+template <bool PRIMARY>
+__global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView sc, DFrame fr, const uint32_t* __restrict__ slot_xy, DPrimary pr,
                                                     DRayQueue qin, const uint32_t* __restrict__ qin_count,
                                                     uint32_t chunk_begin, uint32_t chunk_end,
                                                     DRayQueue qout, uint32_t* qout_count,
@@ -970,8 +990,14 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         long long aux_nx = 0, aux_ny = 0, aux_nz = 0, aux_d = 0;
         if (active) {
         n_shaded++;
-        const float4 r0 = qin.r0[i], r1 = qin.r1[i];
-        const uint2 r2 = qin.r2[i];
+        float4 r0, r1; uint2 r2;
+        if (PRIMARY) { // the root node of a path: throughput 1, depth 1, carries the object id, path node 1
+            f3 po, pd; uint32_t ppix, psmp;
+            primary_ray(fr, slot_xy, pr, i, &po, &pd, &ppix, &psmp);
+            r0 = make_float4(po.x, po.y, po.z, 1.0f);
+            r1 = make_float4(pd.x, pd.y, pd.z, __uint_as_float(ppix));
+            r2 = make_uint2(psmp | (1u << 16) | (1u << 24), 1u);
+        } else { r0 = qin.r0[i]; r1 = qin.r1[i]; r2 = qin.r2[i]; }
         const uint32_t pix = __float_as_uint(r1.w);
         const uint32_t meta = r2.x, node = r2.y;
         const uint32_t sample = meta & 0xffffu, depth = (meta >> 16) & 0xffu;
