@@ -297,6 +297,15 @@ int rr_sample_table(uint16_t samples, uint16_t* xy_out, uint32_t* cell_size_out)
 int rr_render(rr_scene* scene, const rr_camera* camera, const rr_config* config,
               const uint16_t* sample_xy, const rr_frame* out, const volatile int* cancel);
 
+/* The same frame on SEVERAL GPUs from one host process, as the reference host is one process (src/renderer.rs:105-172).
+ * scenes[i] is a handle created with rr_scene_create(scene, device_i, ...) from the SAME flat scene; handle i renders
+ * the 32x8-pixel tiles with (tile_index % n_scenes == i) on its device (one host thread per device inside the call),
+ * the compact per-device buffers are copied peer-to-peer into scenes[0]'s device, de-interleaved there and copied to
+ * `out` (host buffers, as rr_render).  The frame is bit-identical to rr_render's for any n_scenes.  Two handles may sit
+ * on the same device (a rehearsal on one GPU); a handle may take part in one call at a time. */
+int rr_render_multi(rr_scene* const* scenes, uint32_t n_scenes, const rr_camera* camera, const rr_config* config,
+                    const uint16_t* sample_xy, const rr_frame* out, const volatile int* cancel);
+
 /* Progressive form of rr_render.  Stands in for the progressive fill the reference shows while a frame renders:
  * Run::apply_pixels drains the PixelData channel every GUI tick (src/run.rs:506-545) and RendererManager::stop
  * (src/renderer.rs:174-198) ends the frame early.  The frame is rendered in at least `min_passes` device batches of

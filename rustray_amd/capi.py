@@ -21,7 +21,7 @@ _LIB = None
 # every symbol include/rustray_hip.h declares (tests/test_abi.py checks the list against the header)
 EXPORTS = ["rr_device_count", "rr_last_error", "rr_scene_create", "rr_scene_destroy", "rr_scene_update_transforms",
            "rr_scene_update_materials", "rr_scene_set_tuning", "rr_scene_get_tuning",
-           "rr_sample_table", "rr_render", "rr_render_progressive", "rr_region_pixel_count", "rr_render_region_device",
+           "rr_sample_table", "rr_render", "rr_render_multi", "rr_render_progressive", "rr_region_pixel_count", "rr_render_region_device",
            "rr_deinterleave_device", "rr_pick", "rr_scene_last_stats", "rr_post_process", "rr_post_process_device"]
 
 
@@ -59,6 +59,7 @@ def lib():
         L.rr_scene_update_transforms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rr_sample_table.argtypes = [C.c_uint16, C.c_void_p, C.POINTER(C.c_uint32)]
         L.rr_render.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p, C.POINTER(rr_frame), C.c_void_p]
+        L.rr_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p, C.POINTER(rr_frame), C.c_void_p]
         L.rr_render_progressive.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p, C.POINTER(rr_frame),
                                             C.c_uint32, PASS_FN, C.c_void_p, C.c_void_p]
         L.rr_render_region_device.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p,
@@ -219,6 +220,23 @@ class DeviceScene:
         st = rr_frame_stats()
         _check(lib().rr_scene_last_stats(self._h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in rr_frame_stats._fields_}
+
+
+def render_multi(device_scenes, cam: rr_camera, cfg: rr_config, sample_xy=None, aux: bool = True):
+    """rr_render_multi: one frame over several DeviceScene handles (one per GPU) from this one process, into host arrays."""
+    w, h = cam.width, cam.height
+    rgba = np.zeros((h, w, 4), np.uint8)
+    out = dict(rgba=rgba)
+    fr = rr_frame(rgba.ctypes.data, None, None, None)
+    if aux:
+        out["normal"] = np.zeros((h, w, 3), np.float32)
+        out["depth"] = np.zeros((h, w), np.float32)
+        out["object_id"] = np.zeros((h, w), np.uint32)
+        fr = rr_frame(rgba.ctypes.data, out["normal"].ctypes.data, out["depth"].ctypes.data, out["object_id"].ctypes.data)
+    keep, p = _sxy(sample_xy)
+    handles = (C.c_void_p * len(device_scenes))(*[ds._h for ds in device_scenes])
+    _check(lib().rr_render_multi(handles, len(device_scenes), C.byref(cam), C.byref(cfg), p, C.byref(fr), None))
+    return out
 
 
 def deinterleave_device(width, height, tile_w, tile_h, n_ranks, elem_bytes, src_ptr, dst_ptr, device, stream_ptr=None):

@@ -22,6 +22,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rr_kernels.hip"
@@ -99,6 +100,7 @@ struct rr_scene {
     DevBuf acc_rgb, acc_normal, acc_depth, acc_id;
     DevBuf region_xy, trace_order, sample_xy, pool, counters; // region_xy: pixel of each accumulator slot; trace_order: its output index
     DevBuf tmp_out[4];
+    DevBuf multi_part[4], multi_cat[4]; // rr_render_multi: this device's compact buffers; on device slot 0 the concatenation of all
     std::vector<uint32_t> h_region_xy;
     rr_region region_cached{0, 0, 0, 0};
     uint32_t region_w = 0, region_h = 0;
@@ -1104,6 +1106,86 @@ extern "C" int rr_deinterleave_device(uint32_t width, uint32_t height, uint32_t 
     hipLaunchKernelGGL(k_gather_frame, dim3((uint32_t)((total + RR_BLOCK - 1) / RR_BLOCK)), dim3(RR_BLOCK), 0, (hipStream_t)hip_stream,
                        gm->index.as<uint32_t>(), np, words, (const uint32_t*)src, (uint32_t*)dst);
     HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// one frame on several GPUs from ONE host process (the reference host is one process, src/renderer.rs:105-172):
+// one host thread per device renders that device's interleaved tiles, the compact per-device buffers are copied
+// peer-to-peer (xGMI) into device 0, de-interleaved there and copied to the host once.  No collective library is
+// involved: the exchange is n - 1 point-to-point copies of 1 / n of the frame each.
+// ---------------------------------------------------------------------------
+extern "C" int rr_render_multi(rr_scene* const* scenes, uint32_t n_scenes, const rr_camera* cam, const rr_config* cfg,
+                               const uint16_t* sample_xy, const rr_frame* out, const volatile int* cancel) {
+    if (!scenes || n_scenes == 0) return fail(RR_ERR_INVALID_ARGUMENT, "no scenes");
+    if (n_scenes > 64) return fail(RR_ERR_UNSUPPORTED, "%u scene handles", n_scenes);
+    for (uint32_t i = 0; i < n_scenes; i++) {
+        if (!scenes[i]) return fail(RR_ERR_INVALID_ARGUMENT, "scene %u is NULL", i);
+        for (uint32_t j = 0; j < i; j++) if (scenes[j] == scenes[i]) return fail(RR_ERR_INVALID_ARGUMENT, "scene handle %u is passed twice", i);
+        int rc = check_frame_args(scenes[i], cam, cfg);
+        if (rc != RR_OK) return rc;
+    }
+    if (!out || !out->rgba8) return fail(RR_ERR_INVALID_ARGUMENT, "out->rgba8 is required");
+    const uint32_t W = cam->width, H = cam->height, TW = 32, TH = 8; // interleaved 32x8 tiles: tile_index % n == device slot
+    const size_t np = (size_t)W * H;
+    const size_t esz[4] = {4, 12, 4, 4};
+    void* host[4] = {out->rgba8, out->normal, out->depth, out->object_id};
+    std::vector<uint64_t> count(n_scenes), offset(n_scenes);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_scenes; i++) {
+        rr_region rg{TW, TH, n_scenes, i};
+        count[i] = rr_region_pixel_count(W, H, &rg);
+        offset[i] = total; total += count[i];
+    }
+    rr_scene* s0 = scenes[0];
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (uint32_t i = 0; i < n_scenes; i++) locks.emplace_back(scenes[i]->mu); // address order is the caller's: a handle is in one multi call at a time
+    // device 0: the concatenation of the compact buffers (rank order) and the frame-order buffers
+    HIP_TRY(hipSetDevice(s0->device));
+    for (int k = 0; k < 4; k++)
+        if (host[k]) { HIP_TRY(s0->multi_cat[k].reserve(np * esz[k])); HIP_TRY(s0->tmp_out[k].reserve(np * esz[k])); }
+    // every device renders its tiles into its own compact buffers, then pushes them into device 0's concatenation
+    std::vector<int> rcs(n_scenes, RR_OK);
+    std::vector<std::string> errs(n_scenes);
+    auto work = [&](uint32_t i) {
+        rr_scene* s = scenes[i];
+        auto body = [&]() -> int {
+            HIP_TRY(hipSetDevice(s->device));
+            rr_frame dev{};
+            void** devp[4] = {(void**)&dev.rgba8, (void**)&dev.normal, (void**)&dev.depth, (void**)&dev.object_id};
+            for (int k = 0; k < 4; k++) {
+                if (!host[k]) continue;
+                if (i == 0) *devp[k] = (char*)s0->multi_cat[k].p + offset[0] * esz[k]; // device 0 renders straight into its slot
+                else { HIP_TRY(s->multi_part[k].reserve(std::max<uint64_t>(count[i], 1) * esz[k])); *devp[k] = s->multi_part[k].p; }
+            }
+            rr_region rg{TW, TH, n_scenes, i};
+            int rc = render_region_locked(s, cam, cfg, sample_xy, &rg, &dev, false, nullptr, cancel);
+            if (rc != RR_OK) return rc;
+            if (i != 0)
+                for (int k = 0; k < 4; k++)
+                    if (host[k] && count[i])
+                        HIP_TRY(hipMemcpyPeerAsync((char*)s0->multi_cat[k].p + offset[i] * esz[k], s0->device, s->multi_part[k].p, s->device, count[i] * esz[k], nullptr));
+            HIP_TRY(hipStreamSynchronize(nullptr));
+            return RR_OK;
+        };
+        rcs[i] = body();
+        if (rcs[i] != RR_OK) errs[i] = tl_error; // the message lives in the worker's thread-local slot
+    };
+    std::vector<std::thread> threads;
+    for (uint32_t i = 1; i < n_scenes; i++) threads.emplace_back(work, i);
+    work(0);
+    for (auto& t : threads) t.join();
+    for (uint32_t i = 0; i < n_scenes; i++)
+        if (rcs[i] != RR_OK) return fail(rcs[i], "device slot %u: %s", i, errs[i].c_str());
+    HIP_TRY(hipSetDevice(s0->device));
+    for (int k = 0; k < 4; k++) {
+        if (!host[k]) continue;
+        int rc = rr_deinterleave_device(W, H, TW, TH, n_scenes, (uint32_t)esz[k], s0->multi_cat[k].p, s0->tmp_out[k].p, s0->device, nullptr);
+        if (rc != RR_OK) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    for (int k = 0; k < 4; k++)
+        if (host[k]) HIP_TRY(hipMemcpy(host[k], s0->tmp_out[k].p, np * esz[k], hipMemcpyDeviceToHost));
     return RR_OK;
 }
 

@@ -87,3 +87,12 @@ def test_scene_validation_without_gpu():
         rc, _, msg = _create(load_scene("spheres").c_struct())
         assert rc == -3 and "no HIP device" in msg
     assert capi.lib().rr_scene_create(None, 0, C.byref(C.c_void_p())) == -1
+
+
+def test_render_multi_validates_before_touching_a_device():
+    from rustray_amd.flat import rr_camera, rr_config, rr_frame
+    L = capi.lib()
+    assert L.rr_render_multi(None, 0, C.byref(rr_camera()), C.byref(rr_config()), None, C.byref(rr_frame()), None) == -1
+    handles = (C.c_void_p * 2)(None, None)
+    assert L.rr_render_multi(handles, 2, C.byref(rr_camera()), C.byref(rr_config()), None, C.byref(rr_frame()), None) == -1
+    assert "NULL" in L.rr_last_error().decode()

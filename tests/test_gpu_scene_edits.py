@@ -51,7 +51,12 @@ def test_scene_without_items_renders_black_and_accepts_updates(hip):
 
 def test_create_destroy_does_not_leak_device_memory(hip):
     """The BVH4 nodes and the precomputed triangles (the largest scene buffers) were not freed by rr_scene_destroy."""
-    import torch
+    rt = C.CDLL("libamdhip64.so")   # the HIP runtime the library itself is linked against
+
+    def free_bytes():
+        free, total = C.c_size_t(0), C.c_size_t(0)
+        assert rt.hipDeviceSynchronize() == 0 and rt.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
     fs = load_scene("monkey")
     cam = camera_for(fs, 64, 48).c_struct()
     cfg = make_config(samples=1, monte_carlo=False, seed=0)
@@ -60,12 +65,10 @@ def test_create_destroy_does_not_leak_device_memory(hip):
         with hip.DeviceScene(fs, 0) as ds:
             ds.render(cam, cfg)
     cycle()  # first use: code objects, the de-interleave maps, torch's context
-    torch.cuda.synchronize()
-    free0, _ = torch.cuda.mem_get_info(0)
+    free0 = free_bytes()
     for _ in range(12):
         cycle()
-    torch.cuda.synchronize()
-    free1, _ = torch.cuda.mem_get_info(0)
+    free1 = free_bytes()
     assert free0 - free1 < (4 << 20), f"{(free0 - free1) / 2**20:.1f} MiB lost over 12 create / destroy cycles"
 
 
