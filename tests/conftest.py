@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# torch bundles its own HIP runtime; whichever runtime a process loads first serves both torch and librustray_hip.so.
+# Loaded second (after the library has initialised /opt/rocm's runtime), torch finds "No HIP GPUs": import it first,
+# as bench.py does, so that tests that hand torch tensors to the C ABI work whatever subset of the suite is run.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
