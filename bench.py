@@ -174,6 +174,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip rgba_only / rr_render_host / other_configs (profiling runs)")
     ap.add_argument("--rgba-only", action="store_true", help="developer A/B: time the frame without the aux buffers")
+    ap.add_argument("--binning", action="store_true", help="developer A/B: bin deeper levels by (origin cell, direction octant) before tracing")
     ap.add_argument("--tile", default="32x8")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     args = ap.parse_args()
@@ -204,6 +205,8 @@ def main():
     tf = TiledFrame(args.width, args.height, rank, world, tw, th)
     ds = capi.DeviceScene(fs, local_rank)  # scene replicated on every GPU, resident before timing
     ds.set_profiling(True)
+    if args.binning:
+        ds.set_tuning(bin_min_rays=1 << 18)
     camc = cam.c_struct()
 
     def step(aux=not args.rgba_only):
@@ -219,7 +222,7 @@ def main():
         step()
     fence()
     acc = dict(primary_rays=0, secondary_rays=0, shadow_rays=0, shaded_hits=0, ms_trace_closest=0.0, ms_trace_shadow=0.0,
-               ms_shade=0.0, launches_trace_closest=0, launches_trace_shadow=0, launches_shade=0, ms_total=0.0)
+               ms_shade=0.0, launches_trace_closest=0, launches_trace_shadow=0, launches_shade=0, ms_total=0.0, ms_binning=0.0, binned_rays=0)
     t0 = time.perf_counter()
     frame = None
     for _ in range(args.steps):
@@ -296,7 +299,7 @@ def main():
             result["roofline"] = roof
         result["kernel_ms_per_frame"] = {"k_trace_closest": acc["ms_trace_closest"] / args.steps,
                                          "k_trace_shadow": acc["ms_trace_shadow"] / args.steps,
-                                         "k_shade": acc["ms_shade"] / args.steps,
+                                         "k_shade": acc["ms_shade"] / args.steps, "k_bin_*": acc["ms_binning"] / args.steps,
                                          "frame_device_ms": acc["ms_total"] / args.steps}
         if frame is not None:
             result["frame_checksum"] = int(frame["rgba"].to(torch.int64).sum().item())

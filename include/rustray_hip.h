@@ -242,6 +242,8 @@ typedef struct rr_frame_stats {
     uint64_t launches_shade;
     uint64_t batches;       /* device batches of primary samples the frame was cut into */
     uint64_t sliced_levels; /* depth levels whose children did not fit behind them in the ray arena at once */
+    uint64_t binned_rays;   /* secondary rays that were re-ordered by (origin cell, direction octant) before being traced */
+    double ms_binning;      /* device time of that re-ordering (kernel_timing) */
 } rr_frame_stats;
 
 /* Execution knobs of the device path.  None of them changes a single output bit (fixed-point accumulation makes
@@ -255,6 +257,8 @@ typedef struct rr_tuning {
     uint64_t shade_chunk_rays;   /* rays shaded per launch: 0 = 64 Mi (minimum 65536) */
     uint32_t kernel_timing;      /* non-zero: per-launch HIP events fill the ms_* fields of rr_frame_stats */
     uint32_t _pad;
+    uint64_t bin_min_rays;       /* deeper depth levels of at least this many rays are re-ordered by (origin cell, direction
+                                    octant) before they are traced: 0 = never (measured: spawn order is already coherent) */
 } rr_tuning;
 
 typedef struct rr_scene rr_scene; /* opaque */

@@ -711,6 +711,7 @@ static void resolve_timers(rr_scene* s) {
             if (t.kind == 0) { s->stats.ms_trace_closest += ms; s->stats.launches_trace_closest++; }
             else if (t.kind == 1) { s->stats.ms_trace_shadow += ms; s->stats.launches_trace_shadow++; }
             else if (t.kind == 2) { s->stats.ms_shade += ms; s->stats.launches_shade++; }
+            else if (t.kind == 3) { s->stats.ms_binning += ms; }
         }
         s->event_pool.push_back(t.a); s->event_pool.push_back(t.b);
     }
@@ -947,7 +948,30 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
             HIP_TRY(hipEventSynchronize(s->count_ready));
             const uint64_t m = *s->h_count;
             if (m > M - child_base) return fail(RR_ERR_DEVICE, "internal: level %u holds %llu rays, room for %llu", d + 1, (unsigned long long)m, (unsigned long long)(M - child_base));
-            if (m > 0) { const int rc2 = run_level(d + 1, child_base, m, child_count); if (rc2 != RR_OK) return rc2; }
+            if (m == 0) continue;
+            // On request (rr_tuning::bin_min_rays) deeper levels are traced in bins of (origin cell, direction octant) when
+            // the sorted copy fits behind the unsorted one (rr_kernels.hip: ray binning; off by default, it does not pay).
+            uint64_t level_base = child_base;
+            const uint64_t bin_min = s->tuning.bin_min_rays;
+            if (bin_min != 0 && m >= bin_min && M - child_base >= 3 * m + 2ull * RR_BLOCK * (R + 1)) {
+                next_word = (next_word + 31u) & ~31u;
+                int* bounds = (int*)words(8);
+                uint32_t* hist = words(RR_BIN_COUNT);
+                if (bounds && hist) {
+                    const int init[8] = {0x7f7fffff, 0x7f7fffff, 0x7f7fffff, (int)0x80800000, (int)0x80800000, (int)0x80800000, 0, 0}; // ordered(+FLT_MAX) x3, ordered(-FLT_MAX) x3
+                    HIP_TRY(hipMemcpyAsync(bounds, init, sizeof init, hipMemcpyHostToDevice, st));
+                    const DRayQueue qsrc = queue_at(child_base), qdst = queue_at(child_base + m);
+                    const int g = (int)std::min<uint64_t>((m + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)s->n_cus * 8);
+                    ScopedTimer t(s, st, 3);
+                    hipLaunchKernelGGL(k_bin_bounds, dim3(g), dim3(RR_BLOCK), 0, st, qsrc, (uint32_t)m, bounds);
+                    hipLaunchKernelGGL(k_bin_count, dim3(g), dim3(RR_BLOCK), 0, st, qsrc, (uint32_t)m, bounds, hist);
+                    hipLaunchKernelGGL(k_bin_prefix, dim3(1), dim3(1024), 0, st, hist);
+                    hipLaunchKernelGGL(k_bin_scatter, dim3(g), dim3(RR_BLOCK), 0, st, qsrc, qdst, (uint32_t)m, hist);
+                    level_base = child_base + m;
+                    s->stats.binned_rays += m;
+                }
+            }
+            { const int rc2 = run_level(d + 1, level_base, m, child_count); if (rc2 != RR_OK) return rc2; }
         }
         return RR_OK;
     };
@@ -1290,9 +1314,9 @@ extern "C" int rr_math_probe(int op, const float* a, const float* b, const float
 }
 
 #ifdef RR_EXP_UTIL
-extern "C" int rr_exp_util(unsigned long long* out32, int reset) {
-    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_util), sizeof(g_util)) != hipSuccess) return RR_ERR_DEVICE;
-    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_util), z, sizeof(z)) != hipSuccess) return RR_ERR_DEVICE; }
+extern "C" int rr_exp_util(unsigned long long* out64, int reset) {
+    if (out64 && hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_util), sizeof(g_util)) != hipSuccess) return RR_ERR_DEVICE;
+    if (reset) { unsigned long long z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_util), z, sizeof(z)) != hipSuccess) return RR_ERR_DEVICE; }
     return RR_OK;
 }
 #endif

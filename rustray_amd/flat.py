@@ -113,12 +113,13 @@ class rr_frame_stats(C.Structure):
         ("ms_trace_shadow", C.c_double), ("ms_shade", C.c_double),
         ("launches_trace_closest", C.c_uint64), ("launches_trace_shadow", C.c_uint64),
         ("launches_shade", C.c_uint64), ("batches", C.c_uint64), ("sliced_levels", C.c_uint64),
+        ("binned_rays", C.c_uint64), ("ms_binning", C.c_double),
     ]
 
 
 class rr_tuning(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("sample_group", C.c_uint32), ("queue_budget_bytes", C.c_uint64),
-                ("shade_chunk_rays", C.c_uint64), ("kernel_timing", C.c_uint32), ("_pad", C.c_uint32)]
+                ("shade_chunk_rays", C.c_uint64), ("kernel_timing", C.c_uint32), ("_pad", C.c_uint32), ("bin_min_rays", C.c_uint64)]
 
 
 # ---------------------------------------------------------------------------

@@ -36,7 +36,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(flat.rr_camera) == 8 + 128
     assert C.sizeof(flat.rr_config) == 8 + 6 * 4 + 4 + 4
     assert C.sizeof(flat.rr_region) == 16 and C.sizeof(flat.rr_pick_result) == 16
-    assert C.sizeof(flat.rr_tuning) == 32
+    assert C.sizeof(flat.rr_tuning) == 40
 
 
 def test_sample_count_limit():

@@ -426,3 +426,23 @@ def test_cancel_flag_stops_a_frame(hip):
         flag.value = 0
         assert hip.lib().rr_render(ds._h, C.byref(cam), C.byref(cfg), None, C.byref(fr), C.byref(flag)) == 0
         assert np.array_equal(rgba, ds.render(cam, cfg, aux=False)["rgba"])
+
+
+def test_binned_deeper_levels_do_not_change_a_single_bit(hip):
+    """rr_tuning::bin_min_rays: deeper levels re-ordered by (origin cell, direction octant) before they are traced
+    (bounds -> histogram -> prefix -> scatter).  Order never changes the frame: fixed-point accumulators."""
+    fs = load_scene("monkey_room")
+    cam = camera_for(fs, 160, 90).c_struct()
+    cfg = make_config(samples=8, monte_carlo=True, seed=21)
+    with hip.DeviceScene(fs, 0) as ds:
+        ref = ds.render(cam, cfg)
+        st0 = ds.stats()
+        ds.set_tuning(bin_min_rays=1)
+        out = ds.render(cam, cfg)
+        st = ds.stats()
+    assert st0["binned_rays"] == 0 and st["binned_rays"] == st["secondary_rays"] > 10000
+    for k in ("rgba", "depth", "object_id"):
+        assert np.array_equal(out[k], ref[k]), k
+    assert np.array_equal(out["normal"], ref["normal"], equal_nan=True)
+    for k in ("primary_rays", "secondary_rays", "shadow_rays", "shaded_hits"):
+        assert st[k] == st0[k], k

@@ -1,27 +1,33 @@
 #!/usr/bin/env python3
-"""Developer tool: average active lanes per executed step, by kind, from a -DRR_EXP_UTIL build of the library.
-usage: RUSTRAY_HIP_LIB=build/lib_util.so python tools/lane_util.py [scene] [spp]"""
+"""Developer tool: executed wave-steps and their average active lanes, by step kind and by ray kind (closest-hit level 1,
+closest-hit deeper levels, shadow), from a -DRR_EXP_UTIL build of the library.
+usage: RUSTRAY_HIP_LIB=build/lib_util.so python tools/lane_util.py [scene] [spp] [bin]"""
 import ctypes as C
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import argparse
 import bench
 from rustray_amd import capi
 
 scene = sys.argv[1] if len(sys.argv) > 1 else "sponza_syn"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-args = argparse.Namespace(scene=scene, width=1280, height=720, spp=spp, monte_carlo=1)
-fs, cam, cfg = bench.build_workload(args)
+binning = len(sys.argv) > 3 and sys.argv[3] == "bin"
+fs, cam, cfg = bench.build_workload(scene, 1280, 720, spp, 1)
 lib = capi.lib()
-buf = (C.c_ulonglong * 32)()
-names = ["top-level node step", "item setup", "mesh node step", "triangle test", "mesh walk entry"]
+buf = (C.c_ulonglong * 64)()
+steps = {1: "item set-up", 2: "node step (top level + mesh)", 3: "triangle test", 4: "mesh walk entry"}
+kinds = ["closest-hit, level 1", "closest-hit, deeper levels", "shadow rays"]
 with capi.DeviceScene(fs, 0) as ds:
-    for kernel in ("all",):
-        lib.rr_exp_util.argtypes = [C.c_void_p, C.c_int]; lib.rr_exp_util(None, 1)
-        ds.render(cam.c_struct(), cfg, aux=False)
-        lib.rr_exp_util(buf, 0)
-        for i, nm in enumerate(names):
-            lanes, steps = buf[2 * i], buf[2 * i + 1]
-            if steps:
-                print(f"{scene} {nm:22s} wave-steps {steps:12d}  lane-steps {lanes:14d}  avg active lanes {lanes / steps:5.1f} / 64")
+    ds.set_tuning(bin_min_rays=(1 << 18) if binning else 0)
+    lib.rr_exp_util.argtypes = [C.c_void_p, C.c_int]
+    lib.rr_exp_util(None, 1)
+    ds.render(cam.c_struct(), cfg, aux=False)
+    st = ds.stats()
+    lib.rr_exp_util(buf, 0)
+    rays = [st["primary_rays"], st["secondary_rays"], st["shadow_rays"]]
+    print(f"{scene} {spp} spp binning={'on' if binning else 'off'}: rays {rays}")
+    for k, kn in enumerate(kinds):
+        for slot, nm in steps.items():
+            lanes, n = buf[10 * k + 2 * slot], buf[10 * k + 2 * slot + 1]
+            if n:
+                print(f"  {kn:28s} {nm:30s} wave-steps {n:12d}  lane-steps per ray {lanes / max(rays[k], 1):7.2f}  avg active lanes {lanes / n:5.1f} / 64")
