@@ -440,7 +440,8 @@ def test_binned_deeper_levels_do_not_change_a_single_bit(hip):
         ds.set_tuning(bin_min_rays=1)
         out = ds.render(cam, cfg)
         st = ds.stats()
-    assert st0["binned_rays"] == 0 and st["binned_rays"] == st["secondary_rays"] > 10000
+    # levels whose sorted copy does not fit behind them in the arena stay in spawn order
+    assert st0["binned_rays"] == 0 and st["secondary_rays"] >= st["binned_rays"] > 100000
     for k in ("rgba", "depth", "object_id"):
         assert np.array_equal(out[k], ref[k]), k
     assert np.array_equal(out["normal"], ref["normal"], equal_nan=True)
