@@ -171,15 +171,16 @@ class AnimationRun:
         mine = self.my_frames()
         if self.world_size == 1:
             return [(f, done[f]["rgba"]) for f in mine]
+        on_gpu = (not via_cpu) and torch.cuda.is_available() and dist.get_backend() == "nccl"  # RCCL moves device tensors only
         h, w = (done[mine[0]]["rgba"].shape[:2]) if mine else (0, 0)
-        shape = torch.tensor([h, w], dtype=torch.int64)
+        shape = torch.tensor([h, w], dtype=torch.int64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(shape, op=dist.ReduceOp.MAX)  # a rank without frames still needs the shape
         h, w = int(shape[0]), int(shape[1])
         n_max = max(len(self.my_frames(r)) for r in range(self.world_size))
         pad = torch.zeros((n_max, h, w, 4), dtype=torch.uint8)
         for i, f in enumerate(mine):
             pad[i] = torch.from_numpy(np.ascontiguousarray(done[f]["rgba"]))
-        if not via_cpu and torch.cuda.is_available() and dist.get_backend() == "nccl":
+        if on_gpu:
             pad = pad.cuda()
         gl = [torch.empty_like(pad) for _ in range(self.world_size)] if self.rank == 0 else None
         dist.gather(pad, gl, dst=0)
@@ -257,13 +258,9 @@ class TiledFrame:
                 pad[: t.shape[0]] = t
                 if via_cpu:
                     pad = pad.cpu()
+                # gather exists in both backends this runs on ("nccl" = RCCL, "gloo"); the choice is the same on every rank
                 gl = [torch.empty_like(pad) for _ in range(self.world_size)] if self.rank == 0 else None
-                try:
-                    dist.gather(pad, gl, dst=0)
-                except (RuntimeError, NotImplementedError):
-                    # a backend without gather: all_gather moves the same 3.7 MB to every rank instead of one
-                    gl = [torch.empty_like(pad) for _ in range(self.world_size)]
-                    dist.all_gather(gl, pad)
+                dist.gather(pad, gl, dst=0)
                 if self.rank != 0:
                     continue
                 cat = torch.cat([gl[r][: self.counts[r]] for r in range(self.world_size)], dim=0).to(dev)
