@@ -16,7 +16,23 @@ import sys
 tag, name = sys.argv[1], sys.argv[2]
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
-KERNELS = ("k_trace_closest", "k_trace_shadow", "k_shade", "k_raygen", "k_resolve")
+KERNELS = ("k_trace_closest", "k_trace_closest<true>", "k_trace_closest<false>", "k_trace_shadow", "k_shade", "k_shade<true>", "k_shade<false>", "k_resolve")
+
+
+def kname(raw):
+    """'void k_shade<true>(DSceneView, ...)' -> 'k_shade<true>'"""
+    n = raw.split("(")[0].strip()
+    return n[5:] if n.startswith("void ") else n
+
+
+def with_totals(d, combine):
+    """adds 'k_x' = combine over 'k_x<true>' and 'k_x<false>' (level 1 and the deeper levels of one kernel)"""
+    for base in ("k_trace_closest", "k_shade"):
+        parts = [d[k] for k in (base + "<true>", base + "<false>") if k in d]
+        if parts and base not in d:
+            d[base] = combine(parts)
+    return d
+
 N_SIMD, CLOCK_GHZ = 1024, 2.4
 
 
@@ -31,10 +47,18 @@ def counters(sub):
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     if f:
         for r in csv.DictReader(open(f)):
-            a = agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]]
+            a = agg[kname(r["Kernel_Name"])][r["Counter_Name"]]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
-    return agg
+
+    def combine(parts):
+        out = collections.defaultdict(lambda: [0, 0.0])
+        for p in parts:
+            for c, (n, v) in p.items():
+                out[c][0] += n
+                out[c][1] += v
+        return out
+    return with_totals(agg, combine)
 
 
 bench = None
@@ -54,7 +78,9 @@ kernel_ns = {}
 if stats:
     shutil.copy(stats, f"profiles/{name}_kernel_stats_sponza_syn.csv")
     for r in csv.DictReader(open(stats)):
-        kernel_ns[r["Name"].split("(")[0]] = dict(calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), total_ns=float(r["TotalDurationNs"]))
+        kernel_ns[kname(r["Name"])] = dict(calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), total_ns=float(r["TotalDurationNs"]))
+    with_totals(kernel_ns, lambda parts: dict(calls=sum(p["calls"] for p in parts), total_ns=sum(p["total_ns"] for p in parts),
+                                              avg_ns=sum(p["total_ns"] for p in parts) / max(sum(p["calls"] for p in parts), 1)))
 
 # ---- HBM traffic
 fetch, write = counters("pmc_fetch"), counters("pmc_write")
@@ -91,7 +117,9 @@ if sq:
         if k not in sq:
             continue
         d = dict(sq[k])
-        rays = rays_closest if k == "k_trace_closest" else (rays_shadow if k == "k_trace_shadow" else None)
+        rays = {"k_trace_closest": rays_closest, "k_trace_shadow": rays_shadow,
+                "k_trace_closest<true>": bench["rays_per_frame"]["primary"] if bench else None,
+                "k_trace_closest<false>": bench["rays_per_frame"]["secondary"] if bench else None}.get(k)
         if rays and "SQ_INSTS_VALU" in d:
             d["rays_per_frame"] = rays
             d["valu_insts_per_ray"] = d["SQ_INSTS_VALU"] / rays
