@@ -253,7 +253,7 @@ def main():
                                    "(synthetic stand-in for scene/sponza.json: the .glb asset is not available offline)",
                        "outputs": "RGBA8 only (--rgba-only)" if args.rgba_only else "RGBA8 + normal + depth + object_id (PixelData), resident in HBM",
                        "items": len(fs.items), "triangles": fs.n_triangles_instanced(),
-                       "tiling": f"{tw}x{th} tiles interleaved over {world} rank(s), RGBA8 gather to rank 0",
+                       "tiling": f"{tw}x{th} tiles interleaved over {world} rank(s), one packed gather (RGBA8 + aux) to rank 0",
                        "ray_definition": "one Raytracing::trace call: primary + reflection + refraction + shadow"},
             "ms_per_frame": ms_per_step,
             "primary_samples_per_s": primary / elapsed,

@@ -245,27 +245,37 @@ class TiledFrame:
         return self._index
 
     def gather(self, parts: dict, use_device_kernel: bool = False, via_cpu: bool = False) -> Optional[dict]:
-        """via_cpu: stage the compact buffers through host memory (for the gloo backend, which cannot gather
-        device tensors); the default gathers device tensors directly (backend "nccl" = RCCL over xGMI)."""
+        """ONE collective per frame: every rank packs its compact buffers (RGBA8 and whichever aux buffers were rendered)
+        into one byte buffer, rank 0 gathers them (backend "nccl" = RCCL over xGMI, device tensors; `via_cpu` stages
+        through host memory for "gloo", which cannot gather device tensors) and de-interleaves each buffer into frame order."""
         import torch
         import torch.distributed as dist
+        keys = list(parts.keys())
+        flat = {k: parts[k].reshape(self.n_pixels(), -1) for k in keys}
+        gathered = None
+        if self.world_size > 1:
+            dev = flat[keys[0]].device
+            width = {k: flat[k].shape[1] * flat[k].element_size() for k in keys}        # bytes per pixel of each buffer
+            pack = torch.zeros(self.max_count * sum(width.values()), dtype=torch.uint8, device=dev)
+            off = 0
+            for k in keys:   # sections of max_count pixels each, so that every section starts 4-byte aligned on every rank
+                n = self.n_pixels() * width[k]
+                pack[off: off + n] = flat[k].contiguous().view(torch.uint8).reshape(-1)
+                off += self.max_count * width[k]
+            if via_cpu:
+                pack = pack.cpu()
+            gl = [torch.empty_like(pack) for _ in range(self.world_size)] if self.rank == 0 else None
+            dist.gather(pack, gl, dst=0)
+            if self.rank != 0:
+                return None
+            gathered, off = {}, 0
+            for k in keys:
+                rows = [gl[r][off: off + self.counts[r] * width[k]] for r in range(self.world_size)]
+                gathered[k] = torch.cat(rows).to(dev).view(flat[k].dtype).reshape(-1, flat[k].shape[1])
+                off += self.max_count * width[k]
         out = {}
-        for key, t in parts.items():
-            t = t.reshape(self.n_pixels(), -1)
-            if self.world_size > 1:
-                dev = t.device
-                pad = torch.zeros((self.max_count, t.shape[1]), dtype=t.dtype, device=t.device)
-                pad[: t.shape[0]] = t
-                if via_cpu:
-                    pad = pad.cpu()
-                # gather exists in both backends this runs on ("nccl" = RCCL, "gloo"); the choice is the same on every rank
-                gl = [torch.empty_like(pad) for _ in range(self.world_size)] if self.rank == 0 else None
-                dist.gather(pad, gl, dst=0)
-                if self.rank != 0:
-                    continue
-                cat = torch.cat([gl[r][: self.counts[r]] for r in range(self.world_size)], dim=0).to(dev)
-            else:
-                cat = t
+        for k in keys:
+            cat = gathered[k] if gathered is not None else flat[k]
             if use_device_kernel and cat.is_cuda:
                 frame = torch.empty((self.height * self.width, cat.shape[1]), dtype=cat.dtype, device=cat.device)
                 cat = cat.contiguous()
@@ -274,8 +284,8 @@ class TiledFrame:
                                          cat.device.index or 0, torch.cuda.current_stream().cuda_stream)
             else:
                 frame = cat.index_select(0, self._frame_index(cat.device))
-            out[key] = frame.reshape(self.height, self.width, -1)
-        return out if self.rank == 0 else None
+            out[k] = frame.reshape(self.height, self.width, -1)
+        return out
 
 
 def render_region_torch(device_scene: capi.DeviceScene, cam, cfg, tf: TiledFrame, aux: bool = False, sample_xy=None) -> dict:

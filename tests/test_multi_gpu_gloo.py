@@ -28,11 +28,13 @@ def _worker(rank, world, port, w, h, tw, th, ret):
     assert len(xy) == tf.n_pixels()
     x, y = torch.from_numpy(xy[:, 0]), torch.from_numpy(xy[:, 1])
     parts = {"rgba": torch.stack([x % 256, y % 256, (x + y) % 256, torch.full_like(x, 255)], dim=1).to(torch.uint8),
+             "normal": torch.stack([x, y, x - y], dim=1).to(torch.float32),
              "depth": (x * 1000 + y).to(torch.float32),
              "object_id": torch.full((len(xy),), rank + 1, dtype=torch.int32)}
     out = tf.gather(parts)
     if rank == 0:
-        ret["rgba"] = out["rgba"].numpy(); ret["depth"] = out["depth"].numpy(); ret["object_id"] = out["object_id"].numpy()
+        for k in ("rgba", "normal", "depth", "object_id"):
+            ret[k] = out[k].numpy()
     else:
         assert out is None
     dist.barrier()
@@ -50,6 +52,7 @@ def test_two_rank_gather_reassembles_the_frame(w, h, tw, th):
     assert rgba.shape == (h, w, 4)
     assert (rgba[..., 0] == xs % 256).all() and (rgba[..., 1] == ys % 256).all() and (rgba[..., 3] == 255).all()
     assert (ret["depth"][..., 0] == xs * 1000 + ys).all()
+    assert (ret["normal"][..., 0] == xs).all() and (ret["normal"][..., 1] == ys).all() and (ret["normal"][..., 2] == xs - ys).all()
     tiles_x = (w + tw - 1) // tw
     owner = ((ys // th) * tiles_x + xs // tw) % world + 1
     assert (ret["object_id"][..., 0] == owner).all()
