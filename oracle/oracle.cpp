@@ -19,11 +19,14 @@
 // rand 0.8 (StdRng = ChaCha12, seed_from_u64, shuffle, Uniform<f32>),
 // nalgebra 0.32 (dot / cross / normalize / mat*vec evaluation order).
 //
-// PARITY STATUS: "parity unpinned" against the real Rust binary — the reference
-// ships no tests, golden vectors or fixtures for this path and
-// cannot be built offline.  The restatement is pinned only by (a) published
-// known-answer vectors for the primitives it borrows (ChaCha, Philox) and
-// (b) hand-derived unit cases in tests/.
+// PARITY STATUS: pinned STATISTICALLY against outputs of the real Rust binary -- the README renderings the reference
+// ships with their command lines (Readme.md:33-46; tests/golden/ref_shots/, tests/test_ref_shots.py): 43.8 - 52.6 dB
+// PSNR with a mean bias of 0.01 - 0.15 LSB at the renderings' own sample counts.  The reference has no tests or
+// golden vectors and cannot be built offline, so nothing pins it bit for bit; the borrowed
+// primitives (ChaCha, Philox) are pinned by published known-answer vectors, every geometric primitive by
+// hand-derived unit cases in tests/.  Not pinned by any reference output: the bilinear texel path, the
+// receiver-alpha shadow semantic of HEAD (the 2022 binary differed in both), fog, DOF, gamma,
+// normal / roughness / AO / reflectivity maps.
 //
 // Declared divergences from the reference (all documented in DESIGN.md):
 //   D1  jitter() draws come from a counter-based Philox4x32-10 keyed on
