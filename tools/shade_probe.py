@@ -9,7 +9,7 @@ import bench
 from rustray_amd import capi
 
 args = argparse.Namespace(scene=sys.argv[1] if len(sys.argv) > 1 else "sponza_syn", width=1280, height=720, spp=64, monte_carlo=1)
-fs, cam, cfg = bench.build_workload(args)
+fs, cam, cfg = bench.build_workload(args.scene, args.width, args.height, args.spp, args.monte_carlo)
 camc = cam.c_struct()
 
 
