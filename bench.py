@@ -275,8 +275,8 @@ def main():
             launches = acc["launches_trace_closest"]
             avg_ms = acc["ms_trace_closest"] / launches
             rays_per_launch = n_closest_r0 / launches
-            sq, sq_path = newest_profile("r*_sq_counters.json")
-            hbm, hbm_path = newest_profile("r*_hbm_traffic.json")
+            sq, sq_path = newest_profile("r[0-9][0-9]_sq_counters.json")   # the round's final profile (rNNa / rNNb are experiments)
+            hbm, hbm_path = newest_profile("r[0-9][0-9]_hbm_traffic.json")
             roof = {"bound": "valu_issue", "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "kernel": "k_trace_closest", "launches": launches,
                     "avg_launch_ms": avg_ms, "rays_per_launch": rays_per_launch, "achieved": None, "frac": None, "traffic": None}
             if sq and sq.get("workload", "").startswith(f"{fs.name} {args.width}x{args.height} {args.spp}spp"):
