@@ -163,6 +163,7 @@ __shared__ uint32_t s_util_kind; // 0: closest-hit level 1, 1: closest-hit deepe
 #define RR_UTIL(slot) { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63u) == __ffsll((long long)m_) - 1) { \
         atomicAdd(&g_util[10 * s_util_kind + 2 * (slot)], (unsigned long long)__popcll(m_)); atomicAdd(&g_util[10 * s_util_kind + 2 * (slot) + 1], 1ull); } }
 #define RR_UTIL_KIND(k) { s_util_kind = (k); __syncthreads(); }
+#define RR_UTIL_NODE_SLOT ((const void*)nodes4_ptr_ == (const void*)sc.tnodes4 ? 0 : 2)
 #else
 #define RR_UTIL(slot)
 #define RR_UTIL_KIND(k)
@@ -218,7 +219,8 @@ RR_DEV float4 node_row(const DNode4* nodes, uint32_t byte_off) { return *(const 
     }
 #define RR_NODE4_STEP(nodes4, s4, bound)                                                                       \
     {                                                                                                          \
-        RR_UTIL(2) const uint32_t no_ = (uint32_t)cur << 7;                                                    \
+        const void* nodes4_ptr_ = (nodes4); (void)nodes4_ptr_;                                                 \
+        RR_UTIL(RR_UTIL_NODE_SLOT) const uint32_t no_ = (uint32_t)cur << 7;                                                    \
         const float4 rnx = node_row(nodes4, no_ + (s4).nx), rfx = node_row(nodes4, no_ + (s4).fx);             \
         const float4 rny = node_row(nodes4, no_ + (s4).ny), rfy = node_row(nodes4, no_ + (s4).fy);             \
         const float4 rnz = node_row(nodes4, no_ + (s4).nz), rfz = node_row(nodes4, no_ + (s4).fz);             \
@@ -244,7 +246,8 @@ RR_DEV float4 node_row(const DNode4* nodes, uint32_t byte_off) { return *(const 
 // the children are visited does not matter, so the hit children are pushed in slot order and the sort is skipped.
 #define RR_NODE4_STEP_ANY(nodes4, s4, bound)                                                                   \
     {                                                                                                          \
-        RR_UTIL(2) const uint32_t no_ = (uint32_t)cur << 7;                                                    \
+        const void* nodes4_ptr_ = (nodes4); (void)nodes4_ptr_;                                                 \
+        RR_UTIL(RR_UTIL_NODE_SLOT) const uint32_t no_ = (uint32_t)cur << 7;                                                    \
         const float4 rnx = node_row(nodes4, no_ + (s4).nx), rfx = node_row(nodes4, no_ + (s4).fx);             \
         const float4 rny = node_row(nodes4, no_ + (s4).ny), rfy = node_row(nodes4, no_ + (s4).fy);             \
         const float4 rnz = node_row(nodes4, no_ + (s4).nz), rfz = node_row(nodes4, no_ + (s4).fz);             \

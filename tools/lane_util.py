@@ -15,7 +15,7 @@ binning = len(sys.argv) > 3 and sys.argv[3] == "bin"
 fs, cam, cfg = bench.build_workload(scene, 1280, 720, spp, 1)
 lib = capi.lib()
 buf = (C.c_ulonglong * 64)()
-steps = {1: "item set-up", 2: "node step (top level + mesh)", 3: "triangle test", 4: "mesh walk entry"}
+steps = {0: "top-level node step", 1: "item set-up", 2: "mesh node step", 3: "triangle test", 4: "mesh walk entry"}
 kinds = ["closest-hit, level 1", "closest-hit, deeper levels", "shadow rays"]
 with capi.DeviceScene(fs, 0) as ds:
     ds.set_tuning(bin_min_rays=(1 << 18) if binning else 0)
