@@ -96,3 +96,15 @@ def test_render_multi_validates_before_touching_a_device():
     handles = (C.c_void_p * 2)(None, None)
     assert L.rr_render_multi(handles, 2, C.byref(rr_camera()), C.byref(rr_config()), None, C.byref(rr_frame()), None) == -1
     assert "NULL" in L.rr_last_error().decode()
+
+
+def test_header_is_plain_c99_and_links(tmp_path):
+    """include/rustray_hip.h compiled as C99 (-pedantic -Werror) into a C host that links the library and runs the
+    host-side validation paths (tests/native/abi_c99.c)."""
+    import subprocess
+    exe = str(tmp_path / "abi_c99")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "native", "abi_c99.c"),
+                           "-L" + libdir, "-lrustray_hip", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "abi c99 OK" in out.stdout, out.stdout + out.stderr
