@@ -12,7 +12,7 @@ from rustray_amd import capi
 from rustray_amd.renderer import TiledFrame, render_region_torch
 
 args = argparse.Namespace(scene="sponza_syn", width=1280, height=720, spp=128, monte_carlo=1)
-fs, cam, cfg = bench.build_workload(args)
+fs, cam, cfg = bench.build_workload(args.scene, args.width, args.height, args.spp, args.monte_carlo)
 ds = capi.DeviceScene(fs, 0)
 ds.set_profiling(True)
 camc = cam.c_struct()
@@ -21,11 +21,11 @@ for n in (1, 2, 4, 8):
     tf = TiledFrame(args.width, args.height, 0, n, 32, 8)
     tf.world_size_for_gather = 1
     for _ in range(2):
-        render_region_torch(ds, camc, cfg, tf, aux=False)
+        render_region_torch(ds, camc, cfg, tf, aux=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5):
-        render_region_torch(ds, camc, cfg, tf, aux=False)
+        render_region_torch(ds, camc, cfg, tf, aux=True)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 200.0
     st = ds.stats()
