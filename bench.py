@@ -23,8 +23,10 @@ Extra keys (rank 0, N = 1): `rgba_only_ms` (aux buffers not requested), `rr_rend
 Rank 0 prints ONE JSON line with `roofline` and `cpu_baseline` (the C++ restatement in
 oracle/ timed on the host cores over a bounded sample of the same frame).
 
-`roofline`: the dominant kernel k_trace_closest walks a BVH that lives in L2 / Infinity
-Cache (130 MB), so HBM is NOT what bounds it (measured: 8 % of HBM peak); what it runs out
+`roofline`: the dominant kernel is the level-1 build of the closest-hit kernel,
+`k_trace_closest<true>` (8.7 of the frame's 25.4 ms; its row in the rocprofv3 kernel stats
+under profiles/ carries the same average duration).  It walks a BVH that lives in L2 / Infinity
+Cache (130 MB), so HBM is NOT what bounds it (measured: 3 % of HBM peak); what it runs out
 of is vector-instruction issue slots and the latency that keeps them empty.  `bound` is
 therefore "valu_issue": achieved = VALU wave-instructions per ray (SQ_INSTS_VALU of the
 committed profiles/r*_sq_counters.json, a property of code + scene) x rays per launch /
@@ -222,7 +224,8 @@ def main():
         step()
     fence()
     acc = dict(primary_rays=0, secondary_rays=0, shadow_rays=0, shaded_hits=0, ms_trace_closest=0.0, ms_trace_shadow=0.0,
-               ms_shade=0.0, launches_trace_closest=0, launches_trace_shadow=0, launches_shade=0, ms_total=0.0, ms_binning=0.0, binned_rays=0)
+               ms_shade=0.0, launches_trace_closest=0, launches_trace_shadow=0, launches_shade=0, ms_total=0.0, ms_binning=0.0, binned_rays=0,
+               ms_trace_closest_level1=0.0, launches_trace_closest_level1=0)
     t0 = time.perf_counter()
     frame = None
     for _ in range(args.steps):
@@ -269,33 +272,38 @@ def main():
             st = dict(fs.meta["camera"]); st["width"], st["height"] = 320, 180
             small = argparse.Namespace(**vars(args)); small.cpu_spp = 1
             _, ab = cpu_baseline(fs, _Cam.from_state(st), small)
-        # roofline of the dominant kernel (rank 0's launches), see the module docstring
-        n_closest_r0 = acc["primary_rays"] + acc["secondary_rays"]
-        if acc["launches_trace_closest"] > 0:
-            launches = acc["launches_trace_closest"]
-            avg_ms = acc["ms_trace_closest"] / launches
-            rays_per_launch = n_closest_r0 / launches
+        # roofline of the dominant kernel (rank 0's launches), see the module docstring: the level-1 build of the closest-hit
+        # kernel, `k_trace_closest<true>` in the rocprofv3 kernel stats (one launch per batch, the frame is one batch)
+        if acc["launches_trace_closest_level1"] > 0:
+            launches = acc["launches_trace_closest_level1"]
+            avg_ms = acc["ms_trace_closest_level1"] / launches
+            rays_per_launch = acc["primary_rays"] / launches
             sq, sq_path = newest_profile("r[0-9][0-9]_sq_counters.json")   # the round's final profile (rNNa / rNNb are experiments)
             hbm, hbm_path = newest_profile("r[0-9][0-9]_hbm_traffic.json")
-            roof = {"bound": "valu_issue", "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "kernel": "k_trace_closest", "launches": launches,
+            roof = {"bound": "valu_issue", "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "kernel": "k_trace_closest<true>", "launches": launches,
                     "avg_launch_ms": avg_ms, "rays_per_launch": rays_per_launch, "achieved": None, "frac": None, "traffic": None}
-            if sq and sq.get("workload", "").startswith(f"{fs.name} {args.width}x{args.height} {args.spp}spp"):
-                vpr = sq["kernels"]["k_trace_closest"]["valu_insts_per_ray"]
+            k1 = (sq or {}).get("kernels", {}).get("k_trace_closest<true>")
+            if k1 and sq.get("workload", "").startswith(f"{fs.name} {args.width}x{args.height} {args.spp}spp"):
+                vpr = k1["valu_insts_per_ray"]
                 roof["achieved"] = vpr * rays_per_launch / (avg_ms * 1e-3) / 1e9
                 roof["frac"] = roof["achieved"] / VALU_PEAK_GINST
                 roof["valu_wave_insts_per_ray"] = vpr
                 roof["sq_counters"] = sq_path
-                roof["sq_wait_any_frac_of_wave_cycles"] = sq["kernels"]["k_trace_closest"].get("wait_any_frac")
-            if hbm:
-                roof["traffic"] = hbm.get("k_trace_closest_bytes_per_launch")
+                roof["sq_wait_any_frac_of_wave_cycles"] = k1.get("wait_any_frac")
+                roof["sq_wait_inst_any_frac_of_wave_cycles"] = k1.get("wait_inst_any_frac")
+            h1 = (hbm or {}).get("kernels", {}).get("k_trace_closest<true>")
+            if h1:
+                roof["traffic"] = h1["hbm_bytes_per_launch_corrected"]
                 roof["traffic_source"] = hbm_path
-                if roof["traffic"]:
-                    roof["hbm_measured_frac"] = roof["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                roof["hbm_measured_frac"] = roof["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             if ab is not None:
                 bpr = ab["bytes_per_closest_ray"]
                 roof["algorithmic_bytes_per_ray"] = bpr
                 roof["algorithmic_gbs"] = bpr * rays_per_launch / (avg_ms * 1e-3) / 1e9   # cache-served: may exceed HBM peak
                 roof["whole_frame_bytes_per_ray"] = ab["bytes_per_ray"]
+            all_l = acc["launches_trace_closest"]
+            roof["all_levels"] = {"launches": all_l, "avg_launch_ms": acc["ms_trace_closest"] / max(all_l, 1),
+                                  "rays_per_launch": (acc["primary_rays"] + acc["secondary_rays"]) / max(all_l, 1)}
             result["roofline"] = roof
         result["kernel_ms_per_frame"] = {"k_trace_closest": acc["ms_trace_closest"] / args.steps,
                                          "k_trace_shadow": acc["ms_trace_shadow"] / args.steps,

@@ -244,6 +244,8 @@ typedef struct rr_frame_stats {
     uint64_t sliced_levels; /* depth levels whose children did not fit behind them in the ray arena at once */
     uint64_t binned_rays;   /* secondary rays that were re-ordered by (origin cell, direction octant) before being traced */
     double ms_binning;      /* device time of that re-ordering (kernel_timing) */
+    double ms_trace_closest_level1;          /* the part of ms_trace_closest spent on depth level 1 (the primary rays) */
+    uint64_t launches_trace_closest_level1;
 } rr_frame_stats;
 
 /* Execution knobs of the device path.  None of them changes a single output bit (fixed-point accumulation makes

@@ -708,8 +708,9 @@ static void resolve_timers(rr_scene* s) {
     for (auto& t : s->timed) {
         float ms = 0.0f;
         if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
-            if (t.kind == 0) { s->stats.ms_trace_closest += ms; s->stats.launches_trace_closest++; }
-            else if (t.kind == 1) { s->stats.ms_trace_shadow += ms; s->stats.launches_trace_shadow++; }
+            if (t.kind == 0 || t.kind == 4) { s->stats.ms_trace_closest += ms; s->stats.launches_trace_closest++; }
+            if (t.kind == 4) { s->stats.ms_trace_closest_level1 += ms; s->stats.launches_trace_closest_level1++; }
+            if (t.kind == 1) { s->stats.ms_trace_shadow += ms; s->stats.launches_trace_shadow++; }
             else if (t.kind == 2) { s->stats.ms_shade += ms; s->stats.launches_shade++; }
             else if (t.kind == 3) { s->stats.ms_binning += ms; }
         }
@@ -891,7 +892,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         {
             uint32_t* head = words(1);
             if (!head) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise rr_tuning::shade_chunk_rays");
-            ScopedTimer t(s, st, 0);
+            ScopedTimer t(s, st, d == 1 ? 4 : 0);
             const int grid = (int)std::min<uint64_t>((n + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)trace_grid);
             if (d == 1) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, qin, count, head, fr, s->region_xy.as<uint32_t>(), pr, counters);
             else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, qin, count, head, fr, s->region_xy.as<uint32_t>(), pr, counters);

@@ -114,6 +114,7 @@ class rr_frame_stats(C.Structure):
         ("launches_trace_closest", C.c_uint64), ("launches_trace_shadow", C.c_uint64),
         ("launches_shade", C.c_uint64), ("batches", C.c_uint64), ("sliced_levels", C.c_uint64),
         ("binned_rays", C.c_uint64), ("ms_binning", C.c_double),
+        ("ms_trace_closest_level1", C.c_double), ("launches_trace_closest_level1", C.c_uint64),
     ]
 
 
