@@ -97,7 +97,7 @@ struct rr_scene {
     uint32_t arena_factor = 2; // arena rays per primary ray of a batch; doubled after a frame that had to slice levels
     DevBuf sq[3];
     size_t sq_cap = 0;
-    DevBuf acc_rgb, acc_normal, acc_depth, acc_id;
+    DevBuf acc_rgb, acc_normal, acc_depth, acc_id, acc_flags, shade_const;
     DevBuf region_xy, trace_order, sample_xy, pool, counters; // region_xy: pixel of each accumulator slot; trace_order: its output index
     DevBuf tmp_out[4];
     DevBuf multi_part[4], multi_cat[4]; // rr_render_multi: this device's compact buffers; on device slot 0 the concatenation of all
@@ -767,6 +767,15 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     fr.seed_lo = (uint32_t)cfg->seed; fr.seed_hi = (uint32_t)(cfg->seed >> 32);
     fr.n_region_pixels = npix;
 
+    // ---- the shade kernel's constants (scene view + frame), read from device memory
+    {
+        DShadeConst hc;
+        hc.sc = s->view; hc.fr = fr;
+        HIP_TRY(s->shade_const.reserve(sizeof hc));
+        HIP_TRY(hipMemcpyAsync(s->shade_const.p, &hc, sizeof hc, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st)); // `hc` is a stack local
+    }
+
     // ---- sample table
     if (!sample_xy) { // the built-in table depends on the sample count only: built once per count, not once per frame
         if (s->table_samples != cfg->samples) {
@@ -785,12 +794,15 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     HIP_TRY(s->acc_normal.reserve((size_t)npix * 24));
     HIP_TRY(s->acc_depth.reserve((size_t)npix * 8));
     HIP_TRY(s->acc_id.reserve((size_t)npix * 4));
+    HIP_TRY(s->acc_flags.reserve((size_t)npix * 4));
+    HIP_TRY(hipMemsetAsync(s->acc_flags.p, 0, (size_t)npix * 4, st));
     HIP_TRY(hipMemsetAsync(s->acc_rgb.p, 0, (size_t)npix * 24, st));
     HIP_TRY(hipMemsetAsync(s->acc_normal.p, 0, (size_t)npix * 24, st));
     HIP_TRY(hipMemsetAsync(s->acc_depth.p, 0, (size_t)npix * 8, st));
     HIP_TRY(hipMemsetAsync(s->acc_id.p, 0, (size_t)npix * 4, st));
     HIP_TRY(hipMemsetAsync(s->counters.p, 0, RR_CNT_WORDS * 8, st));
-    DAccum acc{s->acc_rgb.as<long long>(), s->acc_normal.as<long long>(), s->acc_depth.as<long long>(), s->acc_id.as<uint32_t>(), (unsigned long long)npix};
+    DAccum acc{s->acc_rgb.as<long long>(), s->acc_normal.as<long long>(), s->acc_depth.as<long long>(), s->acc_id.as<uint32_t>(), (unsigned long long)npix,
+               s->acc_flags.as<uint32_t>()};
     // aux outputs the caller did not ask for are not accumulated at all
     if (!out->normal) acc.normal = nullptr;
     if (!out->depth) acc.depth = nullptr;
@@ -926,9 +938,9 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
                 if (!sq_counts || !shead) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise rr_tuning::shade_chunk_rays");
                 {
                     ScopedTimer t(s, st, 2);
-                    if (d == 1) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, fr, s->region_xy.as<uint32_t>(), pr, qin, count,
+                    if (d == 1) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(RR_BLOCK), 0, st, s->shade_const.as<DShadeConst>(), s->region_xy.as<uint32_t>(), pr, qin, count,
                                                    (uint32_t)c0, (uint32_t)c1, qout, child_count, SQ, sq_counts, segcap, acc, counters);
-                    else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, fr, s->region_xy.as<uint32_t>(), pr, qin, count,
+                    else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(RR_BLOCK), 0, st, s->shade_const.as<DShadeConst>(), s->region_xy.as<uint32_t>(), pr, qin, count,
                                             (uint32_t)c0, (uint32_t)c1, qout, child_count, SQ, sq_counts, segcap, acc, counters);
                 }
                 // The size of the next level is final once the slice's last shade chunk has run: its read-back is enqueued

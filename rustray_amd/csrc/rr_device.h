@@ -171,7 +171,11 @@ struct DAccum {
     long long* depth;  // n
     uint32_t* object_id; // n
     unsigned long long n; // slots = pixels of the region
+    uint32_t* flags;     // n: non-finite contributions seen by the pixel (RR_NF_*), so that k_resolve can give the sums the value
+                         // the reference's f32 sums would have had (a NaN or +inf sample makes the channel 255, src/raytracing.rs:406-417)
 };
+enum : uint32_t { RR_NF_NAN = 1u, RR_NF_PINF = 1u << 3, RR_NF_NINF = 1u << 6,   // << channel (0 r, 1 g, 2 b)
+                  RR_NF_DEPTH_NAN = 1u << 9, RR_NF_NORMAL_NAN = 1u << 10 };      // << component for the normal
 
 // device-side counters (one block of 64-bit words)
 enum {

@@ -714,9 +714,20 @@ RR_DEV float fresnel(f3 incident, f3 normal, float index) {
 // accumulators
 // ---------------------------------------------------------------------------
 RR_DEV long long to_fix(float v, float scale, float clampv) {
-    if (v != v) return 0ll; // NaN contributions are dropped (divergences)
+    if (v != v) return 0ll; // a NaN adds nothing to the fixed-point sum; its pixel is flagged (to_fix_c)
     v = fminf(fmaxf(v, -clampv), clampv);
     return __float2ll_rn(v * scale);
+}
+// A colour contribution of channel `ch`: non-finite values are recorded in `flags` (RR_NF_*), because the reference's f32
+// sum would carry them to the pixel (NaN or +inf -> 255, -inf -> 0, src/raytracing.rs:406-417) while a fixed-point sum cannot.
+RR_DEV uint32_t nonfinite_flags(float r, float g, float b) {
+    if (((r - r) + (g - g)) + (b - b) == 0.0f) return 0u; // x - x is 0 for every finite x and NaN otherwise: one test for the common case
+    uint32_t f = 0u;
+    const float v[3] = {r, g, b};
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++)
+        if (!(rr_abs(v[ch]) <= RR_FLT_MAX)) f |= (v[ch] != v[ch] ? RR_NF_NAN : (v[ch] > 0.0f ? RR_NF_PINF : RR_NF_NINF)) << ch;
+    return f;
 }
 // Adds of one wave to the accumulators, merged: neighbouring lanes that add to the same pixel (the samples of one
 // pixel sit in neighbouring lanes, k_raygen; compaction keeps lane order) are summed first with a segmented scan over
@@ -864,6 +875,12 @@ RR_DEV void primary_ray(const DFrame& fr, const uint32_t* __restrict__ slot_xy, 
 // ---------------------------------------------------------------------------
 // kernel 2: closest hit for a queue of rays
 // ---------------------------------------------------------------------------
+// Scene view + frame constants of k_shade as one device record.  As by-value kernel arguments all 90 dwords stayed live
+// in SGPRs across the kernel's loop and 117 of them were spilled into VGPR lanes; read through a pointer, only what is
+// in use is kept (k_shade -4 %).  The trace kernels keep their by-value arguments: their walks use the same few fields
+// in every step, and re-reading those costs more than the spills did (closest-hit +4 %, shadow +10 %, measured).
+struct DShadeConst { DSceneView sc; DFrame fr; };
+
 // PRIMARY: depth level 1.  The rays are derived from their index (primary_ray), only the 16-B hit record is written;
 // block 0 publishes the level's size for the shade kernel and counts the rays.
 template <bool PRIMARY>
@@ -954,12 +971,17 @@ RR_DEV float4 item_color(const DSceneView& sc, const MatR& m, bool has_uv, f2 uv
 #define RR_SHADE_WAVES 4
 #endif
 template <bool PRIMARY>
-__global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView sc, DFrame fr, const uint32_t* __restrict__ slot_xy, DPrimary pr,
+__global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShadeConst* __restrict__ kc, const uint32_t* __restrict__ slot_xy, DPrimary pr,
                                                     DRayQueue qin, const uint32_t* __restrict__ qin_count,
                                                     uint32_t chunk_begin, uint32_t chunk_end,
                                                     DRayQueue qout, uint32_t* qout_count,
                                                     DShadowQueue sq, uint32_t* sq_counts, uint32_t sq_segcap,
                                                     DAccum acc, unsigned long long* counters) {
+    // The scene view and the frame constants (90 dwords) are read from a small device record where they are needed
+    // instead of arriving as kernel arguments: as arguments they were all live in SGPRs across the whole loop and the
+    // kernel spilled 117 of them into VGPR lanes.
+    const DSceneView& sc = kc->sc;
+    const DFrame& fr = kc->fr;
     const uint32_t n = min(*qin_count, chunk_end);
     const uint32_t lane = threadIdx.x & (RR_WAVE - 1);
     const bool gw = sc.general_w != 0u;
@@ -993,7 +1015,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         bool spawn_refl = false, spawn_refr = false;
         float4 c1_r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1_r1 = c1_r0, c2_r0 = c1_r0, c2_r1 = c1_r0;
         uint2 c1_r2 = make_uint2(0u, 0u), c2_r2 = c1_r2;
-        uint32_t sum_pix = 0xffffffffu, aux_pix = 0xffffffffu;
+        uint32_t sum_pix = 0xffffffffu, aux_pix = 0xffffffffu, nf = 0u;
         long long aux_nx = 0, aux_ny = 0, aux_nz = 0, aux_d = 0;
         if (active) {
         n_shaded++;
@@ -1055,6 +1077,12 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
             aux_pix = pix;
             aux_d = to_fix(hit_dist, RR_DEPTH_SCALE, 1.0e9f);
             aux_nx = to_fix(normal.x, RR_FIX_SCALE, RR_FIX_CLAMP); aux_ny = to_fix(normal.y, RR_FIX_SCALE, RR_FIX_CLAMP); aux_nz = to_fix(normal.z, RR_FIX_SCALE, RR_FIX_CLAMP);
+            if ((normal.x - normal.x) + (normal.y - normal.y) + (normal.z - normal.z) + (hit_dist - hit_dist) != 0.0f) { // rare: something is not finite
+                if (hit_dist != hit_dist) nf |= RR_NF_DEPTH_NAN;
+                if (normal.x != normal.x) nf |= RR_NF_NORMAL_NAN;
+                if (normal.y != normal.y) nf |= RR_NF_NORMAL_NAN << 1;
+                if (normal.z != normal.z) nf |= RR_NF_NORMAL_NAN << 2;
+            }
         }
         // ---- uv (:749-754)
         bool has_uv = false; f2 uv; uv.x = 0.0f; uv.y = 0.0f;
@@ -1145,9 +1173,9 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
         {
             float fa = fog_amount * ao;
             sum_pix = pix;
-            sum_r += to_fix(thr * (fr.fog_color[0] * fa + ambient_color.x), RR_FIX_SCALE, RR_FIX_CLAMP);
-            sum_g += to_fix(thr * (fr.fog_color[1] * fa + ambient_color.y), RR_FIX_SCALE, RR_FIX_CLAMP);
-            sum_b += to_fix(thr * (fr.fog_color[2] * fa + ambient_color.z), RR_FIX_SCALE, RR_FIX_CLAMP);
+            const float kr_ = thr * (fr.fog_color[0] * fa + ambient_color.x), kg_ = thr * (fr.fog_color[1] * fa + ambient_color.y), kb_ = thr * (fr.fog_color[2] * fa + ambient_color.z);
+            nf |= nonfinite_flags(kr_, kg_, kb_);
+            sum_r += to_fix(kr_, RR_FIX_SCALE, RR_FIX_CLAMP); sum_g += to_fix(kg_, RR_FIX_SCALE, RR_FIX_CLAMP); sum_b += to_fix(kb_, RR_FIX_SCALE, RR_FIX_CLAMP);
         }
         // ---- object id (:744, :966-969): the last sample's id, passed through fully transparent hits
         const bool child_idc = idc && spawn_refr && approx_equal(alpha, 0.0f);
@@ -1186,6 +1214,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
             const bool nonzero = (cr != 0.0f) || (cg != 0.0f) || (cb != 0.0f);
             const bool want_shadow = (m.flags & RR_MF_RECEIVE_SHADOW) != 0u && nonzero;
             if (!(m.flags & RR_MF_RECEIVE_SHADOW) && nonzero) {
+                nf |= nonfinite_flags(cr, cg, cb);
                 sum_r += to_fix(cr, RR_FIX_SCALE, RR_FIX_CLAMP); sum_g += to_fix(cg, RR_FIX_SCALE, RR_FIX_CLAMP); sum_b += to_fix(cb, RR_FIX_SCALE, RR_FIX_CLAMP);
             }
             const uint32_t si = sq_base + wave_alloc(sq_count, want_shadow, lane);
@@ -1219,6 +1248,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(DSceneView s
             n_secondary++;
         }
         } // active
+        if (nf) atomicOr(&acc.flags[sum_pix], nf); // rare: a non-finite term (sum_pix is set whenever nf can be)
         accum_merged(acc, sum_pix, sum_r, sum_g, sum_b);
         if ((acc.normal || acc.depth) && __ballot(aux_pix != 0xffffffffu) != 0ull) accum_aux_merged(acc, aux_pix, aux_nx, aux_ny, aux_nz, aux_d);
         {
@@ -1339,8 +1369,10 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DScen
                 factor = 1.0f - shadow_source_alpha;
             }
             sum_pix = __float_as_uint(s2.w);
-            sum_r = to_fix(s2.x * factor, RR_FIX_SCALE, RR_FIX_CLAMP); sum_g = to_fix(s2.y * factor, RR_FIX_SCALE, RR_FIX_CLAMP);
-            sum_b = to_fix(s2.z * factor, RR_FIX_SCALE, RR_FIX_CLAMP);
+            const float vr_ = s2.x * factor, vg_ = s2.y * factor, vb_ = s2.z * factor;
+            const uint32_t nf = nonfinite_flags(vr_, vg_, vb_);
+            sum_r = to_fix(vr_, RR_FIX_SCALE, RR_FIX_CLAMP); sum_g = to_fix(vg_, RR_FIX_SCALE, RR_FIX_CLAMP); sum_b = to_fix(vb_, RR_FIX_SCALE, RR_FIX_CLAMP);
+            if (nf) atomicOr(&acc.flags[sum_pix], nf);
         }
         accum_merged(acc, sum_pix, sum_r, sum_g, sum_b);
         }
@@ -1467,12 +1499,18 @@ __global__ __launch_bounds__(RR_BLOCK) void k_resolve(DFrame fr, const uint32_t*
     else o = slot_out[p]; // position in the region's compact output order
     const double inv_fix = 1.0 / 16777216.0;
     const float n = (float)fr.samples;
+    const uint32_t nf = acc.flags[p];
     float c[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float sum = (float)((double)acc.rgb[(unsigned long long)k * acc.n + p] * inv_fix);
+        // what the reference's f32 sum would hold if a sample was not finite: NaN (also +inf + -inf) or +-inf
+        const bool pinf = (nf >> (3 + k)) & 1u, ninf = (nf >> (6 + k)) & 1u;
+        if (((nf >> k) & 1u) || (pinf && ninf)) sum = __builtin_nanf("");
+        else if (pinf) sum = __builtin_inff();
+        else if (ninf) sum = -__builtin_inff();
         float v = sum / n;
-        c[k] = rs_min(v, 1.0f);
+        c[k] = rs_min(v, 1.0f); // f32::min: NaN.min(1.0) = 1.0
     }
     uint32_t r, g, b;
     if (fr.gamma) {
@@ -1485,10 +1523,15 @@ __global__ __launch_bounds__(RR_BLOCK) void k_resolve(DFrame fr, const uint32_t*
     if (normal && acc.normal) {
         f3 nn = mk3((float)((double)acc.normal[p] * inv_fix) / n, (float)((double)acc.normal[acc.n + p] * inv_fix) / n,
                     (float)((double)acc.normal[2ull * acc.n + p] * inv_fix) / n);
+        if (nf & (RR_NF_NORMAL_NAN * 7u)) { // a NaN sample normal poisons its component, and through the norm all three
+            if (nf & RR_NF_NORMAL_NAN) nn.x = __builtin_nanf("");
+            if (nf & (RR_NF_NORMAL_NAN << 1)) nn.y = __builtin_nanf("");
+            if (nf & (RR_NF_NORMAL_NAN << 2)) nn.z = __builtin_nanf("");
+        }
         nn = normalize3(nn); // 0/0 = NaN on all-miss pixels, as in the reference (:426)
         normal[3ull * o] = nn.x; normal[3ull * o + 1] = nn.y; normal[3ull * o + 2] = nn.z;
     }
-    if (depth && acc.depth) depth[o] = (float)((double)acc.depth[p] * (1.0 / 65536.0)) / n;
+    if (depth && acc.depth) depth[o] = (nf & RR_NF_DEPTH_NAN) ? __builtin_nanf("") : (float)((double)acc.depth[p] * (1.0 / 65536.0)) / n;
     if (object_id && acc.object_id) object_id[o] = acc.object_id[p];
 }
 
