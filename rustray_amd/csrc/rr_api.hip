@@ -906,8 +906,8 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
             if (!head) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise rr_tuning::shade_chunk_rays");
             ScopedTimer t(s, st, d == 1 ? 4 : 0);
             const int grid = (int)std::min<uint64_t>((n + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)trace_grid);
-            if (d == 1) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, qin, count, head, fr, s->region_xy.as<uint32_t>(), pr, counters);
-            else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, qin, count, head, fr, s->region_xy.as<uint32_t>(), pr, counters);
+            if (d == 1) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, qin, count, head, s->shade_const.as<DShadeConst>(), s->region_xy.as<uint32_t>(), pr, counters);
+            else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, qin, count, head, s->shade_const.as<DShadeConst>(), s->region_xy.as<uint32_t>(), pr, counters);
         }
         const bool spawns = d <= R; // the deepest level spawns nothing (k_shade: depth <= max_recursion)
         const uint64_t child_base = d == 1 ? 0 : base + n;
@@ -1279,15 +1279,18 @@ extern "C" int rr_pick(rr_scene* s, const rr_camera* cam, int x, int y, rr_pick_
     memcpy(fr.view_inv, cam->view_inverse, 64);
     fr.width = cam->width; fr.height = cam->height; fr.samples = 1; fr.cell_size = 1; fr.n_region_pixels = 1;
     DevBuf scratch;
-    HIP_TRY(scratch.reserve(256));
-    // layout: [0] region_xy, [4] sample_xy (2 x u16), [64] hit, [96] count, [100] head, [128] counters
+    HIP_TRY(scratch.reserve(256 + sizeof(DShadeConst)));
+    // layout: [0] region_xy, [4] sample_xy (2 x u16), [64] hit, [96] count, [100] head, [128] counters, [256] scene view + frame constants
     char* b = scratch.as<char>();
     uint32_t h_xy = (uint32_t)x | ((uint32_t)y << 16);
     HIP_TRY(hipMemset(b, 0, 256));
     HIP_TRY(hipMemcpy(b, &h_xy, 4, hipMemcpyHostToDevice));
     DRayQueue q{nullptr, nullptr, nullptr, (uint4*)(b + 64)};
     DPrimary pr{(const uint16_t*)(b + 4), 0ull, 1u, 1u};
-    hipLaunchKernelGGL(k_trace_closest<true>, dim3(1), dim3(RR_BLOCK), 0, nullptr, s->view, q, (uint32_t*)(b + 96), (uint32_t*)(b + 100), fr,
+    DShadeConst hc;
+    hc.sc = s->view; hc.fr = fr;
+    HIP_TRY(hipMemcpy(b + 256, &hc, sizeof hc, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_trace_closest<true>, dim3(1), dim3(RR_BLOCK), 0, nullptr, s->view, q, (uint32_t*)(b + 96), (uint32_t*)(b + 100), (const DShadeConst*)(b + 256),
                        (const uint32_t*)b, pr, (unsigned long long*)(b + 128));
     uint32_t hit[4];
     HIP_TRY(hipMemcpy(hit, b + 64, 16, hipMemcpyDeviceToHost));

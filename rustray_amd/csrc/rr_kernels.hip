@@ -885,9 +885,10 @@ struct DShadeConst { DSceneView sc; DFrame fr; };
 // block 0 publishes the level's size for the shade kernel and counts the rays.
 template <bool PRIMARY>
 __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_closest(DSceneView sc, DRayQueue q, uint32_t* __restrict__ q_count,
-                                                            uint32_t* head, DFrame fr, const uint32_t* __restrict__ slot_xy, DPrimary pr,
+                                                            uint32_t* head, const DShadeConst* __restrict__ kc, const uint32_t* __restrict__ slot_xy, DPrimary pr,
                                                             unsigned long long* counters) {
     __shared__ int s_stack[RR_STACK_DEPTH * RR_BLOCK];
+    const DFrame& fr = kc->fr; // read once per packet (primary_ray): not worth 49 SGPRs across the walks
     RR_UTIL_KIND(PRIMARY ? 0u : 1u)
     uint32_t n;
     if (PRIMARY) {
