@@ -99,6 +99,7 @@ struct rr_scene {
     size_t sq_cap = 0;
     DevBuf acc_rgb, acc_normal, acc_depth, acc_id, acc_flags, shade_const;
     DevBuf region_xy, trace_order, sample_xy, pool, counters; // region_xy: pixel of each accumulator slot; trace_order: its output index
+    std::vector<DevBuf> pool_more; // further segments of per-batch counters, for batches with very many launches (kept for the next frame)
     DevBuf tmp_out[4];
     DevBuf multi_part[4], multi_cat[4]; // rr_render_multi: this device's compact buffers; on device slot 0 the concatenation of all
     std::vector<uint32_t> h_region_xy;
@@ -565,6 +566,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         }
         const uint32_t f = item_flags(ih, cache, full, s->tex_width);
         d.flags = f;
+        if (f & RR_IF_OCCLUDER_ALPHA_TEX) s->view.any_alpha_occluder = 1u;
     }
 
     // ---- top level: always present (even for one item), so the kernels have a single traversal path.
@@ -669,8 +671,11 @@ extern "C" int rr_scene_update_materials(rr_scene* s, const rr_material* materia
     HIP_TRY(hipSetDevice(s->device));
     std::vector<DMaterial> dmat(n_materials);
     for (uint32_t i = 0; i < n_materials; i++) dmat[i] = make_dmaterial(materials[i], s->tex_width);
-    for (size_t i = 0; i < s->item_host.size(); i++)
+    s->view.any_alpha_occluder = 0u;
+    for (size_t i = 0; i < s->item_host.size(); i++) {
         s->h_items[i].flags = item_flags(s->item_host[i], materials[s->item_host[i].material_cache], materials[s->item_host[i].material], s->tex_width);
+        if (s->h_items[i].flags & RR_IF_OCCLUDER_ALPHA_TEX) s->view.any_alpha_occluder = 1u;
+    }
     HIP_TRY(hipDeviceSynchronize());
     if (n_materials) HIP_TRY(hipMemcpy(s->materials.p, dmat.data(), dmat.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
     if (!s->h_items.empty()) HIP_TRY(hipMemcpy(s->items.p, s->h_items.data(), s->h_items.size() * sizeof(DItem), hipMemcpyHostToDevice));
@@ -888,8 +893,21 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     const uint32_t L = s->n_enabled_lights;
 
     uint32_t next_word = 0;
+    size_t pool_segment = 0; // 0 = s->pool, k = s->pool_more[k - 1]
+    // Per-batch counters come out of zeroed segments of POOL_WORDS words.  A segment is never recycled inside a batch
+    // (launches still in flight and the levels above in the recursion hold pointers into it); a batch with more
+    // launches than one segment serves (a deeply branching scene in a very small ray arena) gets another one.
     auto words = [&](uint32_t n) -> uint32_t* {
-        if (next_word + n > POOL_WORDS) return nullptr;
+        if (next_word + n > POOL_WORDS) {
+            if (pool_segment == s->pool_more.size()) {
+                if (s->pool_more.size() >= 255) return nullptr; // 4 GB of counters: something else is wrong
+                s->pool_more.emplace_back();
+                if (s->pool_more.back().reserve(POOL_WORDS * 4) != hipSuccess) { s->pool_more.pop_back(); return nullptr; }
+            }
+            pool = s->pool_more[pool_segment++].as<uint32_t>();
+            if (hipMemsetAsync(pool, 0, POOL_WORDS * 4, st) != hipSuccess) return nullptr;
+            next_word = 0;
+        }
         uint32_t* p = pool + next_word; next_word += n; return p;
     };
     // One depth level: rays [base, base + n) of the arena, their count also in the device word `count`.
@@ -903,7 +921,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         if (d == 1) { qin.r0 = nullptr; qin.r1 = nullptr; qin.r2 = nullptr; qin.hit = s->hit1.as<uint4>(); }
         {
             uint32_t* head = words(1);
-            if (!head) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise rr_tuning::shade_chunk_rays");
+            if (!head) return fail(RR_ERR_UNSUPPORTED, "out of memory for the per-launch counters of a batch");
             ScopedTimer t(s, st, d == 1 ? 4 : 0);
             const int grid = (int)std::min<uint64_t>((n + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)trace_grid);
             if (d == 1) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, qin, count, head, s->shade_const.as<DShadeConst>(), s->region_xy.as<uint32_t>(), pr, counters);
@@ -923,7 +941,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         for (uint64_t s0 = 0; s0 < n; s0 += slice) {
             const uint64_t s1 = std::min<uint64_t>(s0 + slice, n);
             uint32_t* child_count = words(1);
-            if (!child_count) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise rr_tuning::shade_chunk_rays");
+            if (!child_count) return fail(RR_ERR_UNSUPPORTED, "out of memory for the per-launch counters of a batch");
             const DRayQueue qout = queue_at(child_base);
             for (uint64_t c0 = s0; c0 < s1; c0 += chunk) {
                 if (cancel && *cancel) { (void)hipStreamSynchronize(st); return fail(RR_ERR_CANCELLED, "cancelled"); }
@@ -935,7 +953,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
                 next_word = (next_word + 31u) & ~31u; // the append counters start on a 128-B line
                 uint32_t* sq_counts = words(RR_SQ_SHARDS * RR_SQ_STRIDE);
                 uint32_t* shead = words(1);
-                if (!sq_counts || !shead) return fail(RR_ERR_UNSUPPORTED, "too many launches in one batch; raise rr_tuning::shade_chunk_rays");
+                if (!sq_counts || !shead) return fail(RR_ERR_UNSUPPORTED, "out of memory for the per-launch counters of a batch");
                 {
                     ScopedTimer t(s, st, 2);
                     if (d == 1) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(RR_BLOCK), 0, st, s->shade_const.as<DShadeConst>(), s->region_xy.as<uint32_t>(), pr, qin, count,
@@ -993,6 +1011,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     for (uint64_t first = 0; first < total_primary; first += B) {
         if (cancel && *cancel) { (void)hipStreamSynchronize(st); return fail(RR_ERR_CANCELLED, "cancelled"); }
         const uint32_t n_batch = (uint32_t)std::min<uint64_t>(B, total_primary - first);
+        pool = s->pool.as<uint32_t>(); pool_segment = 0;
         HIP_TRY(hipMemsetAsync(pool, 0, POOL_WORDS * 4, st));
         next_word = 0;
         uint32_t* level1_count = words(1);

@@ -118,7 +118,7 @@ struct DSceneView {
     uint32_t n_lights;
     const DNode4* tnodes4;  // the top level over item world boxes, same form (one item per leaf)
     int32_t tlas_root4;      // node index, a leaf code (one item), or RR_SENTINEL (empty scene)
-    uint32_t _pad0;
+    uint32_t any_alpha_occluder; // some item's material has an alpha map: its shadow attenuation can be NaN (k_shade, want_shadow)
     uint32_t general_w;      // some trans_inv has a w row other than (0,0,0,1)
 };
 

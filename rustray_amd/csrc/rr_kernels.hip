@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
         bool spawn_refl = false, spawn_refr = false;
         float4 c1_r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1_r1 = c1_r0, c2_r0 = c1_r0, c2_r1 = c1_r0;
         uint2 c1_r2 = make_uint2(0u, 0u), c2_r2 = c1_r2;
-        uint32_t sum_pix = 0xffffffffu, aux_pix = 0xffffffffu, nf = 0u;
+        uint32_t sum_pix = 0xffffffffu, aux_pix = 0xffffffffu, nf = 0u, pix_of_nf = 0u;
         long long aux_nx = 0, aux_ny = 0, aux_nz = 0, aux_d = 0;
         if (active) {
         n_shaded++;
@@ -1029,6 +1029,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
             r2 = make_uint2(psmp | (1u << 16) | (1u << 24), 1u);
         } else { r0 = qin.r0[i]; r1 = qin.r1[i]; r2 = qin.r2[i]; }
         const uint32_t pix = __float_as_uint(r1.w);
+        pix_of_nf = pix;
         const uint32_t meta = r2.x, node = r2.y;
         const uint32_t sample = meta & 0xffffu, depth = (meta >> 16) & 0xffu;
         const bool idc = ((meta >> 24) & 1u) != 0u;
@@ -1170,6 +1171,10 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
             w_refr = thr * (((kr < 1.0f) ? ((1.0f - kr) * (1.0f - alpha)) : (1.0f - alpha)) * g);
         }
 
+        // The reference multiplies the light sum by (1 - reflectivity), alpha, (1 - fog) and the AO texel AFTER the light
+        // loop (:922-991): a NaN in any of them (a map sampled at a NaN uv: acos beyond 1 at a sphere's pole) poisons the
+        // pixel even when the light sum is exactly zero or there is no light at all, where no contribution carries it here.
+        if (w_light != w_light) nf |= RR_NF_NAN * 7u;
         // ---- constant part: fog colour and ambient / emissive (:977-994)
         {
             float fa = fog_amount * ao;
@@ -1213,7 +1218,11 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
             const float cg = ((L.color[1] * (specular_color.y * light_power + base_color.y * dot_light)) * intensity) * w_light;
             const float cb = ((L.color[2] * (specular_color.z * light_power + base_color.z * dot_light)) * intensity) * w_light;
             const bool nonzero = (cr != 0.0f) || (cg != 0.0f) || (cb != 0.0f);
-            const bool want_shadow = (m.flags & RR_MF_RECEIVE_SHADOW) != 0u && nonzero;
+            // A light term that is exactly zero stays zero whatever the shadow query says, so its ray is not traced -- unless
+            // an occluder with an alpha map exists: the reference samples that map at the RECEIVER's uv of the OCCLUDER's
+            // hit point (:905), which for a sphere receiver can be acos of a value beyond 1 = NaN, and 0 * NaN = NaN reaches
+            // the pixel (found by tools/fuzz_parity.py: a white pixel in the reference, a dark one here).
+            const bool want_shadow = (m.flags & RR_MF_RECEIVE_SHADOW) != 0u && (nonzero || sc.any_alpha_occluder != 0u);
             if (!(m.flags & RR_MF_RECEIVE_SHADOW) && nonzero) {
                 nf |= nonfinite_flags(cr, cg, cb);
                 sum_r += to_fix(cr, RR_FIX_SCALE, RR_FIX_CLAMP); sum_g += to_fix(cg, RR_FIX_SCALE, RR_FIX_CLAMP); sum_b += to_fix(cb, RR_FIX_SCALE, RR_FIX_CLAMP);
@@ -1249,7 +1258,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
             n_secondary++;
         }
         } // active
-        if (nf) atomicOr(&acc.flags[sum_pix], nf); // rare: a non-finite term (sum_pix is set whenever nf can be)
+        if (nf) atomicOr(&acc.flags[pix_of_nf], nf); // rare: a non-finite term
         accum_merged(acc, sum_pix, sum_r, sum_g, sum_b);
         if ((acc.normal || acc.depth) && __ballot(aux_pix != 0xffffffffu) != 0ull) accum_aux_merged(acc, aux_pix, aux_nx, aux_ny, aux_nz, aux_d);
         {

@@ -4,7 +4,7 @@ import pytest
 
 from rustray_amd.flat import FlatScene, Item, Light, Material, MeshData, make_config
 from rustray_amd.scene import Scene
-from tests.helpers import camera_for
+from tests.helpers import camera_for, compare_frames
 from tests.test_gpu_parity import assert_parity
 
 pytestmark = pytest.mark.gpu
@@ -139,3 +139,27 @@ def test_deep_mesh_tree_keeps_within_the_traversal_stack(hip, oracle):
     _cam(fs, eye=(0.5, 0.8, 5.0), direction=(-0.1, -0.15, -1.0))
     out, _ = _check(hip, oracle, fs, w=128, h=128)
     assert (out["object_id"] == 2).sum() > 1000
+
+
+@pytest.mark.parametrize("name", ["fuzz_alpha", "fuzz_234", "fuzz_568"])
+def test_non_finite_samples_reach_the_pixel_as_in_the_reference(hip, oracle, name):
+    """Scenes reduced from tools/fuzz_parity.py mismatches (tests/golden/fuzz_*.npz).  The reference's f32 sums carry a
+    NaN sample to the pixel (NaN.min(1.0) = 1.0 -> 255, src/raytracing.rs:406-417): fixed-point sums cannot, so k_shade /
+    k_trace_shadow flag the pixel and k_resolve reproduces the value.
+      fuzz_alpha: a sphere with flipped normals shadowed by a mesh with an alpha map.  The light term is exactly 0, but the
+                  map is sampled at the RECEIVER's uv of the occluder's hit point (:905): acos(> 1) = NaN, 0 * NaN = NaN;
+      fuzz_234:   a reflectivity map sampled at a NaN uv at a sphere's pole, no light: color * (1 - NaN) with color = 0;
+      fuzz_568:   several such items, semi-transparent and invisible ones, refraction index below 1."""
+    from rustray_amd.flat import FlatScene
+    import os
+    from tests.helpers import GOLDEN
+    fs = FlatScene.load(os.path.join(GOLDEN, name + ".npz"))
+    w, h = fs.meta["wh"]
+    cam = camera_for(fs, w, h).c_struct()
+    cfg = make_config(**fs.meta["kw"])
+    with hip.DeviceScene(fs, 0) as ds:
+        out = ds.render(cam, cfg)
+    ref = oracle.render(fs.c_struct(), cam, cfg, n_threads=8)
+    res = compare_frames(out, ref)
+    assert res["n_rgb_over"] == 0 and res["n_id_diff"] == 0 and res["nan_mismatch"] == 0, res
+    assert int((ref["rgba"][..., :3] == 255).all(axis=-1).sum()) >= 1   # the white pixels are there
