@@ -349,6 +349,20 @@ int rr_deinterleave_device(uint32_t width, uint32_t height, uint32_t tile_w, uin
 /* Single-ray query at the pixel centre (reference src/raytracing.rs:237-273). */
 int rr_pick(rr_scene* scene, const rr_camera* camera, int x, int y, rr_pick_result* out);
 
+/* Closest-hit queries for a batch of caller-supplied rays: Raytracing::trace(ray, false, false, depth)
+ * (reference src/raytracing.rs:429-490) for each of them, the generalisation of rr_pick (which is one such query for
+ * a pixel-centre ray).  origins / directions: n * 3 floats (host); directions are used as given (trace does not
+ * normalise).  `depth` is the recursion depth the candidate filter sees: reflection-only items are candidates for
+ * depth > 1 only (:454).  out[i].item_index = 0xffffffff when nothing is hit. */
+typedef struct rr_ray_hit {
+    uint32_t hit;        /* 0 = None */
+    uint32_t item_index;
+    uint32_t object_id;  /* ShapeBasics::id of the item */
+    uint32_t face_id;    /* as Shape::intersect reports it: triangle index, + n_triangles for back faces; 0 for spheres */
+    float distance;      /* toi */
+} rr_ray_hit;
+int rr_trace_rays(rr_scene* scene, const float* origins, const float* directions, uint32_t n, uint32_t depth, rr_ray_hit* out);
+
 /* Post-processing of a finished frame (reference run_post_processing, src/post_processing.rs:123-181, called from
  * Run::post_processing, src/run.rs:588-600): outline on object-id edges (:98-121), then cavity = curvature of the
  * normal buffer (:77-96), clamp, truncate to u8.  Consumes exactly the buffers rr_render produces.

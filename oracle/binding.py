@@ -133,6 +133,28 @@ def post_process(rgba, normal, object_id, cavity: bool, outline: bool):
     return out
 
 
+def trace_rays(fs_struct, origins, dirs, depth: int = 2, for_shadow: bool = False, brute_force: bool = False):
+    """Raytracing::trace for given rays: (found, item, face, toi) arrays."""
+    o = np.ascontiguousarray(origins, np.float32); d = np.ascontiguousarray(dirs, np.float32)
+    out = np.zeros((len(o), 4), np.uint32)
+    lib().rro_trace_rays(C.byref(fs_struct), _p(o), _p(d), C.c_uint32(len(o)), C.c_uint32(depth), C.c_int(int(for_shadow)), C.c_int(int(brute_force)), _p(out))
+    return out[:, 0].astype(bool), out[:, 1].astype(np.int32), out[:, 2].copy(), out[:, 3].copy().view(np.float32)
+
+
+class ray_log:
+    """with ray_log(cap) as log: render(..., n_threads=1) -> log.rays() = every trace() call of the render, in order."""
+    def __init__(self, cap=1 << 16):
+        self.buf = np.zeros((cap, 12), np.uint32); self.n = C.c_uint32(0)
+    def __enter__(self):
+        lib().rro_set_ray_log(_p(self.buf), C.c_uint32(len(self.buf)), C.byref(self.n)); return self
+    def __exit__(self, *a):
+        lib().rro_set_ray_log(None, C.c_uint32(0), None)
+    def rays(self):
+        b = self.buf[:self.n.value]
+        return dict(origin=b[:, 0:3].copy().view(np.float32), dir=b[:, 3:6].copy().view(np.float32), depth=b[:, 6].copy(), for_shadow=b[:, 7].astype(bool),
+                    found=b[:, 8].astype(bool), item=b[:, 9].astype(np.int32), face=b[:, 10].copy(), toi=b[:, 11].copy().view(np.float32))
+
+
 def pick(fs_struct, cam, x, y):
     r = rr_pick_result()
     lib().rro_pick(C.byref(fs_struct), C.byref(cam), C.c_int(x), C.c_int(y), C.byref(r))

@@ -620,7 +620,24 @@ static bool item_intersect(const OScene& sc, const rr_item& it, const Ray& ray, 
 // ---------------------------------------------------------------------------
 struct TraceHit { float toi; V3 normal; int item; uint32_t face_id; };
 
+static bool trace_impl(const OScene& sc, const Ray& ray, bool stop_on_first_hit, bool for_shadow, uint16_t depth, TraceHit* out);
+
+// Test-only ray log (rro_set_ray_log): every trace() call of a render appends 12 words -- origin, direction, depth, for_shadow, found,
+// item, face id, toi -- so that a frame mismatch can be replayed ray by ray through rr_trace_rays.  Use with n_threads = 1.
+static uint32_t* g_ray_log = nullptr; static uint32_t g_ray_log_cap = 0; static uint32_t* g_ray_log_n = nullptr;
 static bool trace(const OScene& sc, const Ray& ray, bool stop_on_first_hit, bool for_shadow, uint16_t depth, TraceHit* out) {
+    const bool found = trace_impl(sc, ray, stop_on_first_hit, for_shadow, depth, out);
+    if (g_ray_log && *g_ray_log_n < g_ray_log_cap) {
+        uint32_t* w = g_ray_log + 12 * (size_t)(*g_ray_log_n)++;
+        const float f[6] = {ray.origin.x, ray.origin.y, ray.origin.z, ray.dir.x, ray.dir.y, ray.dir.z};
+        std::memcpy(w, f, 24);
+        w[6] = depth; w[7] = for_shadow; w[8] = found; w[9] = found ? (uint32_t)out->item : 0xffffffffu; w[10] = found ? out->face_id : 0u;
+        const float t = found ? out->toi : 0.0f; std::memcpy(&w[11], &t, 4);
+    }
+    return found;
+}
+
+static bool trace_impl(const OScene& sc, const Ray& ray, bool stop_on_first_hit, bool for_shadow, uint16_t depth, TraceHit* out) {
     tl_kind = for_shadow ? 1 : 0;
     const rr_flat_scene* fs = sc.fs;
     struct Cand { int item; float dist; };
@@ -1345,6 +1362,23 @@ int rro_pick(const rr_flat_scene* fs, const rr_camera* cam, int x, int y, rr_pic
     std::memset(res, 0, sizeof *res);
     if (trace(sc, ray, false, false, 1, &h)) {
         res->hit = 1; res->object_id = fs->items[h.item].id; res->item_index = (uint32_t)h.item; res->distance = h.toi;
+    }
+    return 0;
+}
+
+int rro_set_ray_log(uint32_t* buf, uint32_t cap, uint32_t* count) { g_ray_log = buf; g_ray_log_cap = cap; g_ray_log_n = count; if (count) *count = 0; return 0; }
+
+// Raytracing::trace for a batch of given rays (closest hit, or the shadow form): the ray-level oracle of rr_trace_rays.
+// out: 4 x u32 per ray = (found, item index, face id, bits(toi)); face id as the reference reports it (+ n_triangles for back faces).
+int rro_trace_rays(const rr_flat_scene* fs, const float* origins, const float* dirs, uint32_t n, uint32_t depth, int for_shadow, int brute_force, uint32_t* out) {
+    OScene sc; sc.fs = fs; sc.brute_force = brute_force != 0;
+    sc.prepare();
+    for (uint32_t i = 0; i < n; i++) {
+        Ray ray{load3(origins + 3 * i), load3(dirs + 3 * i)};
+        TraceHit h;
+        const bool found = trace(sc, ray, for_shadow != 0, for_shadow != 0, (uint16_t)depth, &h);
+        out[4 * i] = found ? 1u : 0u; out[4 * i + 1] = found ? (uint32_t)h.item : 0xffffffffu; out[4 * i + 2] = found ? h.face_id : 0u;
+        float t = found ? h.toi : 0.0f; std::memcpy(&out[4 * i + 3], &t, 4);
     }
     return 0;
 }

@@ -22,7 +22,7 @@ _LIB = None
 EXPORTS = ["rr_device_count", "rr_last_error", "rr_scene_create", "rr_scene_destroy", "rr_scene_update_transforms",
            "rr_scene_update_materials", "rr_scene_set_tuning", "rr_scene_get_tuning",
            "rr_sample_table", "rr_render", "rr_render_multi", "rr_render_progressive", "rr_region_pixel_count", "rr_render_region_device",
-           "rr_deinterleave_device", "rr_pick", "rr_scene_last_stats", "rr_post_process", "rr_post_process_device"]
+           "rr_deinterleave_device", "rr_pick", "rr_trace_rays", "rr_scene_last_stats", "rr_post_process", "rr_post_process_device"]
 
 
 class RustrayHipError(RuntimeError):
@@ -67,6 +67,7 @@ def lib():
         L.rr_deinterleave_device.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.rr_pick.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.c_int, C.c_int, C.POINTER(rr_pick_result)]
+        L.rr_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.rr_scene_last_stats.argtypes = [C.c_void_p, C.POINTER(rr_frame_stats)]
         L.rr_scene_update_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.rr_scene_set_tuning.argtypes = [C.c_void_p, C.POINTER(rr_tuning)]
@@ -212,6 +213,14 @@ class DeviceScene:
             setattr(t, k, int(v) & 0xffffffffffffffff)
         t.struct_size = C.sizeof(rr_tuning)
         _check(lib().rr_scene_set_tuning(self._h, C.byref(t)))
+
+    def trace_rays(self, origins, dirs, depth: int = 2):
+        """rr_trace_rays: closest hits of caller-supplied rays -> (found, item, face, toi) arrays."""
+        o = np.ascontiguousarray(origins, np.float32); d = np.ascontiguousarray(dirs, np.float32)
+        n = len(o)
+        out = np.zeros((n, 5), np.uint32)
+        _check(lib().rr_trace_rays(self._h, o.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), C.c_uint32(n), C.c_uint32(depth), out.ctypes.data_as(C.c_void_p)))
+        return out[:, 0].astype(bool), out[:, 1].astype(np.int32), out[:, 3].copy(), out[:, 4].copy().view(np.float32)
 
     def set_profiling(self, on: bool):
         self.set_tuning(kernel_timing=1 if on else 0)

@@ -84,11 +84,14 @@ struct rr_scene {
     DevBuf items, nodes4, tnodes4, tris, trix, attrs, face_slot, materials, textures, texels, lights;
     DSceneView view{};
     std::vector<DItem> h_items;
+    std::vector<uint32_t> h_slot_face; // per mesh triangle: leaf-order slot -> original face index (rr_trace_rays reports the reference's face id)
     std::vector<ItemHost> item_host; // what rr_scene_update_materials needs to rebuild the item flag words
     std::vector<uint32_t> tex_width;
     uint32_t n_materials = 0;
     uint32_t n_enabled_lights = 0;
     uint32_t tlas_node_capacity = 0;
+    double tlas_reach[3] = {0.0, 0.0, 0.0}; // the top level's boxes are padded for ray origins within +-tlas_reach (build_tlas)
+    double tlas_floor[3] = {0.0, 0.0, 0.0}; // ... and never for less than this: the items' own extent
     int tlas_depth_limit = RR_TLAS_MAX_DEPTH, blas_depth_limit = RR_BLAS_MAX_DEPTH; // shares of the traversal stack, see rr_scene_create
     // frame state (grown on demand, reused across frames)
     DevBuf hit1;      // hit records of depth level 1 (the primary rays are derived from their index, not stored)
@@ -358,34 +361,78 @@ static void fill_item_matrices(DItem& d, const float* trans, const float* inv) {
     d.tr2 = make_float4(trans[2], trans[6], trans[10], trans[14]);
 }
 
-// world AABB of an item = box of the 8 transformed local-bbox corners
-// (Bounded::aabb, reference src/shape/mod.rs:48-78), computed in double and padded
-static void world_box(const rr_item& it, float* lo, float* hi) {
-    double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+// ---------------------------------------------------------------------------
+// top level: world boxes over the items
+// ---------------------------------------------------------------------------
+// The reference has no world-space test: a ray is moved into an item's space with the item's f32 inverse matrix and
+// tested there against the local box (Shape::intersect_b_box, src/shape/mod.rs:80-105).  The top-level tree may only
+// skip an item if that local test would fail, so an item's world box is the exact box of its transformed local corners
+// (Bounded::aabb, src/shape/mod.rs:48-78; in double) grown by a bound on how far the f32 local ray can sit from the
+// true one, mapped back to world space.  With M, N the given matrix and inverse, t, t' their translations, u = 2^-24,
+// and origins with |o_c| <= reach_c:  the local ray is  N o + t' + do,  N d + dd  with  |do| <= g (|N| |o| + |t'|),
+// |dd| <= g |N| |d|  (g = 16 u covers the four-term dot products and the local slab test's own rounding), so a point of
+// it maps to the world point  (o + s d) + [E o + e + M do] + s [E d + M dd],  E = M N - I,  e = M t' + t  (N is an f32
+// inverse: E is of the order u cond(M)).  s |d| is at most reach + the box's own extent, which bounds the last term.
+// Far from the origin, or with a badly conditioned transform, this is orders of magnitude more than float spacing
+// (tools/fuzz_parity.py far: a sheared sphere 1e5 away needs 15 units on a 10-unit box); on ordinary scenes it is
+// ~1e-6 of the scene size.  An inverse with a projective bottom row gets an unbounded box (always a candidate).
+struct WorldBox { double lo[3], hi[3]; };
+static WorldBox exact_world_box(const DItem& it) {
+    WorldBox b;
+    const float4 rows[3] = {it.tr0, it.tr1, it.tr2};
+    for (int r = 0; r < 3; r++) { b.lo[r] = 1e300; b.hi[r] = -1e300; }
     for (int c = 0; c < 8; c++) {
-        double p[3] = {(c & 1) ? it.bbox_max[0] : it.bbox_min[0], (c & 2) ? it.bbox_max[1] : it.bbox_min[1], (c & 4) ? it.bbox_max[2] : it.bbox_min[2]};
+        const double p[3] = {(c & 1) ? it.bmax[0] : it.bmin[0], (c & 2) ? it.bmax[1] : it.bmin[1], (c & 4) ? it.bmax[2] : it.bmin[2]};
         for (int r = 0; r < 3; r++) {
-            double v = (double)it.trans[r] * p[0] + (double)it.trans[4 + r] * p[1] + (double)it.trans[8 + r] * p[2] + (double)it.trans[12 + r];
-            l[r] = std::min(l[r], v); h[r] = std::max(h[r], v);
+            const double v = (double)rows[r].x * p[0] + (double)rows[r].y * p[1] + (double)rows[r].z * p[2] + (double)rows[r].w;
+            b.lo[r] = std::min(b.lo[r], v); b.hi[r] = std::max(b.hi[r], v);
         }
     }
+    return b;
+}
+static void padded_world_box(const DItem& it, const WorldBox& b, const double reach[3], float* lo, float* hi) {
+    const double M[3][4] = {{it.tr0.x, it.tr0.y, it.tr0.z, it.tr0.w}, {it.tr1.x, it.tr1.y, it.tr1.z, it.tr1.w}, {it.tr2.x, it.tr2.y, it.tr2.z, it.tr2.w}};
+    const double N[3][4] = {{it.inv0.x, it.inv0.y, it.inv0.z, it.inv0.w}, {it.inv1.x, it.inv1.y, it.inv1.z, it.inv1.w}, {it.inv2.x, it.inv2.y, it.inv2.z, it.inv2.w}};
+    const bool affine = it.inv3.x == 0.0f && it.inv3.y == 0.0f && it.inv3.z == 0.0f && it.inv3.w == 1.0f;
+    const double g = 16.0 / 16777216.0;
     for (int r = 0; r < 3; r++) {
-        double e = (std::max(std::fabs(l[r]), std::fabs(h[r])) + (h[r] - l[r])) * 1e-5 + 1e-30;
-        lo[r] = (float)(l[r] - e); hi[r] = (float)(h[r] + e);
-        if (!std::isfinite(lo[r])) lo[r] = -3.0e38f;
-        if (!std::isfinite(hi[r])) hi[r] = 3.0e38f;
+        double pad = 0.0;
+        for (int c = 0; c < 3; c++) {
+            double e = (r == c) ? -1.0 : 0.0, a = 0.0;
+            for (int k = 0; k < 3; k++) { e += M[r][k] * N[k][c]; a += std::fabs(M[r][k]) * std::fabs(N[k][c]); }
+            const double extent = std::max(std::fabs(b.lo[c]), std::fabs(b.hi[c]));
+            pad += (std::fabs(e) + g * a) * (2.0 * reach[c] + extent);
+        }
+        double et = M[r][3], at = 0.0;
+        for (int k = 0; k < 3; k++) { et += M[r][k] * N[k][3]; at += std::fabs(M[r][k]) * std::fabs(N[k][3]); }
+        pad += std::fabs(et) + g * at;
+        pad = 2.0 * pad + 1e-6 * std::max(std::fabs(b.lo[r]), std::fabs(b.hi[r])) + 1e-30; // + float rounding of the box and of the walk's plane distances
+        lo[r] = (float)(b.lo[r] - pad); hi[r] = (float)(b.hi[r] + pad);
+        if (!affine || !std::isfinite(lo[r]) || lo[r] < -3.0e38f) lo[r] = -3.0e38f;
+        if (!affine || !std::isfinite(hi[r]) || hi[r] > 3.0e38f) hi[r] = 3.0e38f;
     }
 }
 
-static int build_tlas(rr_scene* s, const std::vector<rr_item>& items, std::vector<DNode4>* tlas4, int32_t* root4) {
-    uint32_t n = (uint32_t)items.size();
+// Builds the top-level tree over s->h_items for ray origins within +-reach (grown to cover the items themselves: the
+// origins of secondary and shadow rays lie on them).
+static int build_tlas(rr_scene* s, const double want_reach[3], std::vector<DNode4>* tlas4, int32_t* root4) {
+    uint32_t n = (uint32_t)s->h_items.size();
     tlas4->clear();
+    for (int c = 0; c < 3; c++) s->tlas_reach[c] = want_reach[c];
     if (n == 0) { // empty scene: every walk ends at once
         *root4 = (int32_t)0x80000000; // RR_SENTINEL
         return RR_OK;
     }
+    std::vector<WorldBox> exact(n);
+    for (uint32_t i = 0; i < n; i++) {
+        exact[i] = exact_world_box(s->h_items[i]);
+        for (int c = 0; c < 3; c++) {
+            const double m = std::max(std::fabs(exact[i].lo[c]), std::fabs(exact[i].hi[c])) * 1.001 + 0.01; // + the shadow bias along the normal
+            if (std::isfinite(m)) s->tlas_reach[c] = std::max(s->tlas_reach[c], m);
+        }
+    }
     std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
-    for (uint32_t i = 0; i < n; i++) world_box(items[i], &lo[3 * (size_t)i], &hi[3 * (size_t)i]);
+    for (uint32_t i = 0; i < n; i++) padded_world_box(s->h_items[i], exact[i], s->tlas_reach, &lo[3 * (size_t)i], &hi[3 * (size_t)i]);
     rr::BvhResult r;
     if (!rr::build_bvh(lo.data(), hi.data(), n, 1, s->tlas_depth_limit, &r))
         return fail(RR_ERR_UNSUPPORTED, "scene has too many items (%u) for the top-level depth limit", n);
@@ -403,6 +450,44 @@ static int build_tlas(rr_scene* s, const std::vector<rr_item>& items, std::vecto
     *root4 = rr::collapse_bvh4(r, s->tlas_depth_limit, false, tlas4, &pending);
     if (pending > s->tlas_depth_limit) return fail(RR_ERR_UNSUPPORTED, "top level: BVH4 stack bound exceeded");
     return RR_OK;
+}
+
+// Ray origins of the coming launch reach out to +-need: rebuilds the top level when its boxes were padded for less
+// (a camera far outside the scene), or for more than 16x as much (the camera came back).
+static int ensure_tlas_reach(rr_scene* s, const double need[3]) {
+    bool grow = false, shrink = false;
+    for (int c = 0; c < 3; c++) {
+        if (need[c] > s->tlas_reach[c]) grow = true;
+        if (s->tlas_reach[c] > 16.0 * std::max(need[c], s->tlas_floor[c])) shrink = true;
+    }
+    if (!grow && !shrink) return RR_OK;
+    double want[3];
+    for (int c = 0; c < 3; c++) want[c] = 2.0 * need[c]; // build_tlas raises it to the items' own extent
+    std::vector<DNode4> tlas4; int32_t root4 = 0;
+    int rc = build_tlas(s, want, &tlas4, &root4);
+    if (rc != RR_OK) return rc;
+    if (tlas4.size() > s->tlas_node_capacity)
+        return fail(RR_ERR_DEVICE, "top-level rebuild needs %zu nodes, capacity %u", tlas4.size(), s->tlas_node_capacity);
+    HIP_TRY(hipDeviceSynchronize());
+    if (!tlas4.empty()) HIP_TRY(hipMemcpy(s->tnodes4.p, tlas4.data(), tlas4.size() * sizeof(DNode4), hipMemcpyHostToDevice));
+    s->view.tlas_root4 = root4;
+    return RR_OK;
+}
+// bound on the primary-ray origins of a camera (primary_ray: view_inv * (proj_inv * (sx, sy, -1, 1)).xyz1, |sx|, |sy| <= smax)
+static void camera_reach(const rr_camera* cam, const rr_config* cfg, double need[3]) {
+    const double aperture = cfg ? std::max(1.0, (double)cfg->aperture_size) : 1.0;
+    const double smax = 1.0 + 2.0 * (1.0 + aperture * cam->width / 800.0) * (2.0 / std::max(1u, std::min(cam->width, cam->height)));
+    const double v[4] = {smax, smax, 1.0, 1.0};
+    double pp[3];
+    for (int k = 0; k < 3; k++) {
+        pp[k] = 0.0;
+        for (int j = 0; j < 4; j++) pp[k] += std::fabs((double)cam->projection_inverse[4 * j + k]) * v[j];
+    }
+    for (int c = 0; c < 3; c++) {
+        double m = std::fabs((double)cam->view_inverse[12 + c]);
+        for (int k = 0; k < 3; k++) m += std::fabs((double)cam->view_inverse[4 * k + c]) * pp[k];
+        need[c] = m * 1.001;
+    }
 }
 
 extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** out) {
@@ -503,6 +588,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         for (uint32_t slot = 0; slot < nt; slot++) {
             uint32_t f = r.order[slot];
             all_face_slot[fs_base + f] = slot;
+            s->h_slot_face.push_back(f);
             const uint32_t* ix = m.indices + 3 * (size_t)f;
             const float *a = m.positions + 3 * (size_t)ix[0], *b = m.positions + 3 * (size_t)ix[1], *c = m.positions + 3 * (size_t)ix[2];
             DTri t;
@@ -575,9 +661,10 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     std::vector<DNode4> tlas4;
     int32_t tlas_root4 = (int32_t)0x80000000; // RR_SENTINEL: empty scene
     {
-        std::vector<rr_item> items(fs->items, fs->items + fs->n_items);
-        rc = build_tlas(s.get(), items, &tlas4, &tlas_root4);
+        const double none[3] = {0.0, 0.0, 0.0};
+        rc = build_tlas(s.get(), none, &tlas4, &tlas_root4);
         if (rc != RR_OK) return rc;
+        for (int c = 0; c < 3; c++) s->tlas_floor[c] = s->tlas_reach[c];
     }
     s->tlas_node_capacity = std::max<uint32_t>((uint32_t)tlas4.size(), fs->n_items ? fs->n_items : 1u); // room for rebuilds after transform updates
 
@@ -629,23 +716,21 @@ extern "C" int rr_scene_update_transforms(rr_scene* s, const float* trans, const
     HIP_TRY(hipSetDevice(s->device));
     uint32_t n = (uint32_t)s->h_items.size();
     bool general_w = false;
-    std::vector<rr_item> tmp(n);
     for (uint32_t i = 0; i < n; i++) {
         const float *t = trans + 16 * (size_t)i, *ti = trans_inv + 16 * (size_t)i;
         if (!finite16(t) || !finite16(ti)) return fail(RR_ERR_INVALID_ARGUMENT, "item %u: non-finite transform", i);
         fill_item_matrices(s->h_items[i], t, ti);
         if (!(ti[3] == 0.0f && ti[7] == 0.0f && ti[11] == 0.0f && ti[15] == 1.0f)) general_w = true;
-        memset(&tmp[i], 0, sizeof(rr_item));
-        memcpy(tmp[i].trans, t, 64);
-        for (int k = 0; k < 3; k++) { tmp[i].bbox_min[k] = s->h_items[i].bmin[k]; tmp[i].bbox_max[k] = s->h_items[i].bmax[k]; }
     }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(s->items.p, s->h_items.data(), n * sizeof(DItem), hipMemcpyHostToDevice));
     s->view.general_w = general_w ? 1u : 0u;
     {
         std::vector<DNode4> tlas4; int32_t root4 = 0;
-        int rc = build_tlas(s, tmp, &tlas4, &root4);
+        const double none[3] = {0.0, 0.0, 0.0};
+        int rc = build_tlas(s, none, &tlas4, &root4); // the next frame's camera grows the reach again if it has to
         if (rc != RR_OK) return rc;
+        for (int c = 0; c < 3; c++) s->tlas_floor[c] = s->tlas_reach[c];
         if (tlas4.size() > s->tlas_node_capacity)
             return fail(RR_ERR_DEVICE, "top-level rebuild needs %zu nodes, capacity %u", tlas4.size(), s->tlas_node_capacity);
         if (!tlas4.empty()) HIP_TRY(hipMemcpy(s->tnodes4.p, tlas4.data(), tlas4.size() * sizeof(DNode4), hipMemcpyHostToDevice));
@@ -758,6 +843,13 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     resolve_timers(s); // launches of an earlier frame nobody asked about must not leak into this frame's stats
     memset(&s->stats, 0, sizeof s->stats);
     if (npix == 0) return RR_OK;
+
+    { // the top level's boxes must be padded for this camera's distance from the origin
+        double need[3];
+        camera_reach(cam, cfg, need);
+        int rc = ensure_tlas_reach(s, need);
+        if (rc != RR_OK) return rc;
+    }
 
     // ---- frame constants
     DFrame fr;
@@ -1292,6 +1384,12 @@ extern "C" int rr_pick(rr_scene* s, const rr_camera* cam, int x, int y, rr_pick_
     if (x < 0 || y < 0 || (uint32_t)x >= cam->width || (uint32_t)y >= cam->height) return fail(RR_ERR_INVALID_ARGUMENT, "pixel (%d,%d) outside %ux%u", x, y, cam->width, cam->height);
     std::lock_guard<std::mutex> lk(s->mu);
     HIP_TRY(hipSetDevice(s->device));
+    {
+        double need[3];
+        camera_reach(cam, nullptr, need);
+        int rc = ensure_tlas_reach(s, need);
+        if (rc != RR_OK) return rc;
+    }
     DFrame fr;
     memset(&fr, 0, sizeof fr);
     memcpy(fr.proj_inv, cam->projection_inverse, 64);
@@ -1318,6 +1416,69 @@ extern "C" int rr_pick(rr_scene* s, const rr_camera* cam, int x, int y, rr_pick_
     if ((int32_t)hit[1] >= 0) {
         out->hit = 1; out->item_index = hit[1]; out->object_id = s->h_items[hit[1]].id;
         memcpy(&out->distance, &hit[0], 4);
+    }
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// ray queries: Raytracing::trace for caller-supplied rays (the closest-hit kernel of the deeper levels on a queue that
+// the host fills), rr_pick generalised
+// ---------------------------------------------------------------------------
+extern "C" int rr_trace_rays(rr_scene* s, const float* origins, const float* directions, uint32_t n, uint32_t depth, rr_ray_hit* out) {
+    if (!s || (n && (!origins || !directions || !out))) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (depth == 0 || depth > 255u) return fail(RR_ERR_INVALID_ARGUMENT, "depth %u (1 .. 255)", depth);
+    if (n == 0) return RR_OK;
+    if (n > 0x7fffff00u) return fail(RR_ERR_UNSUPPORTED, "%u rays in one call", n);
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIP_TRY(hipSetDevice(s->device));
+    std::vector<float4> r0(n), r1(n);
+    std::vector<uint2> r2(n);
+    {
+        double need[3] = {0.0, 0.0, 0.0};
+        for (uint32_t i = 0; i < n; i++)
+            for (int c = 0; c < 3; c++) {
+                const double a = std::fabs((double)origins[3 * (size_t)i + c]) * 1.001;
+                if (std::isfinite(a)) need[c] = std::max(need[c], a);
+            }
+        int rc = ensure_tlas_reach(s, need);
+        if (rc != RR_OK) return rc;
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        r0[i] = make_float4(origins[3 * (size_t)i], origins[3 * (size_t)i + 1], origins[3 * (size_t)i + 2], 1.0f);
+        r1[i] = make_float4(directions[3 * (size_t)i], directions[3 * (size_t)i + 1], directions[3 * (size_t)i + 2], 0.0f);
+        r2[i] = make_uint2(depth << 16, 1u);
+    }
+    DevBuf b0, b1, b2, bh, bc;
+    HIP_TRY(b0.reserve((size_t)n * 16)); HIP_TRY(b1.reserve((size_t)n * 16)); HIP_TRY(b2.reserve((size_t)n * 8)); HIP_TRY(bh.reserve((size_t)n * 16));
+    HIP_TRY(bc.reserve(64));
+    HIP_TRY(hipMemcpy(b0.p, r0.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b1.p, r1.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b2.p, r2.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    uint32_t words[16] = {n, 0u}; // [0] the level's size, [1] the fetch head
+    HIP_TRY(hipMemcpy(bc.p, words, sizeof words, hipMemcpyHostToDevice));
+    DRayQueue q{b0.as<float4>(), b1.as<float4>(), b2.as<uint2>(), bh.as<uint4>()};
+    DFrame fr;
+    memset(&fr, 0, sizeof fr);
+    DPrimary pr{nullptr, 0ull, 0u, 1u};
+    const int grid = (int)std::min<uint64_t>(((uint64_t)n + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)s->n_cus * RR_TRACE_WAVES);
+    hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(RR_BLOCK), 0, nullptr, s->view, q, bc.as<uint32_t>(), bc.as<uint32_t>() + 1,
+                       (const DShadeConst*)nullptr, (const uint32_t*)nullptr, pr, (unsigned long long*)nullptr);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint4> hits(n);
+    HIP_TRY(hipMemcpy(hits.data(), bh.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) {
+        rr_ray_hit& h = out[i];
+        memset(&h, 0, sizeof h);
+        h.item_index = 0xffffffffu;
+        if ((int32_t)hits[i].y >= 0) {
+            const DItem& it = s->h_items[hits[i].y];
+            h.hit = 1u; h.item_index = hits[i].y; h.object_id = it.id;
+            memcpy(&h.distance, &hits[i].x, 4);
+            if (!(it.flags & RR_IF_SPHERE)) { // leaf-order slot + side bits -> the reference's face id
+                const uint32_t slot = hits[i].z & 0x3fffffffu, back = hits[i].z >> 31;
+                h.face_id = s->h_slot_face[it.tri_base + slot] + (back ? it.n_tris : 0u);
+            }
+        }
     }
     return RR_OK;
 }

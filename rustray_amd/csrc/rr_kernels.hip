@@ -478,6 +478,37 @@ RR_DEV void trace_closest_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, 
     }
 }
 
+// Rays with a non-finite component (a NaN normal, e.g. from a normal map on a sphere whose tangent degenerates, reflects
+// into one).  The reference has no special case for them and its arithmetic decides: in item-local space such a ray
+// is NaN in all components of its origin or direction, ray_toi_with_ball's comparisons are then all false and EVERY
+// candidate sphere reports Some(NaN); a triangle's toi comes out NaN or infinite and fails `toi <= max_toi`.  The
+// candidate loop (src/raytracing.rs:466-487) keeps the first such sphere in (bbox distance, item) order, since nothing
+// compares smaller than NaN, and the hit shades with NaN position and normal (texel (0, 0), finite ambient term).
+// The top-level walk has no defined order for these rays (NaN passes or fails a slab test by the instruction used), so they take this walk over the items
+// instead: exact for spheres; meshes are skipped, which is what the reference's triangle test amounts to.
+RR_DEV bool ray_nonfinite(f3 o, f3 d) {
+    const float z = ((o.x - o.x) + (o.y - o.y) + (o.z - o.z)) + ((d.x - d.x) + (d.y - d.y) + (d.z - d.z)); // x - x: 0 for finite x, NaN otherwise
+    return z != 0.0f;
+}
+RR_DEV void trace_closest_nonfinite(const DSceneView& sc, f3 o, f3 d, uint32_t depth, Closest* best) {
+    best->found = false; best->t = RR_FLT_MAX; best->item = -1; best->face = 0u; best->key = 0.0f;
+    Closest first = *best; // the first candidate in the reference's order that is hit at all
+    for (int idx = 0; idx < (int)sc.n_items; idx++) {
+        const DItem& it = sc.items[idx];
+        const uint32_t flags = it.flags;
+        if (!(flags & RR_IF_SPHERE) || !item_passes(flags, false, depth)) continue;
+        LRay lr = inverse_ray(it, o, d, sc.general_w != 0u);
+        float key, t; bool inside;
+        if (!aabb_cast(it.bmin, it.bmax, lr, (flags & RR_IF_SOLID_BASE) != 0u, &key) || key != key) continue;
+        if (!ray_ball(it.radius, lr, (flags & RR_IF_SOLID_BASE) != 0u, &t, &inside)) continue;
+        if (!first.found || key < first.key || (key == first.key && idx < first.item)) { first.found = true; first.t = t; first.item = idx; first.key = key; }
+        if (t == t && (!best->found || t < best->t || (t == best->t && (key < best->key || (key == best->key && idx < best->item))))) {
+            best->found = true; best->t = t; best->item = idx; best->key = key;
+        }
+    }
+    if (first.found && first.t != first.t) *best = first; // a NaN toi is never replaced (`toi < best` is false)
+}
+
 // Shadow rays stop at the first ITEM (in bbox-distance order) that is hit at all
 // (reference src/raytracing.rs:483-486), not at the nearest hit.
 struct ShadowSel { float key; int item; bool found; bool within; float t; uint32_t face; };
@@ -937,7 +968,8 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_closest(DSce
                 depth = (q.r2[i].x >> 16) & 0xffu;
             }
             Closest best;
-            trace_closest_ray(sc, ro, rd, depth, s_stack, &best);
+            if (ray_nonfinite(ro, rd)) trace_closest_nonfinite(sc, ro, rd, depth, &best);
+            else trace_closest_ray(sc, ro, rd, depth, s_stack, &best);
             q.hit[i] = make_uint4(__float_as_uint(best.t), (uint32_t)(best.found ? best.item : -1), best.face, 0u);
         }
     }

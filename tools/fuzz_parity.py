@@ -2,7 +2,7 @@
 """Developer tool: HIP path against the oracle on N seeded random scenes (the generator of tests/test_gpu_random.py) with
 random frame sizes, sample counts (up to 64), recursion depths (up to 9), fog / gamma / depth of field, and with the
 binning and small-arena paths switched on for some seeds.  Counts frames that differ by more than 1 LSB or whose path
-trees differ.  usage (on the GPU box): python tools/fuzz_parity.py [N] [basic|rich]"""
+trees differ.  usage (on the GPU box): python tools/fuzz_parity.py [N] [basic|rich|far|farbasic]"""
 import sys, time
 sys.path.insert(0, '.')
 import torch  # noqa
@@ -110,36 +110,81 @@ def rich_scene(seed):
     return fs
 
 
-MODE = sys.argv[2] if len(sys.argv) > 2 else "basic"
-bad = 0
-t0 = time.time()
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-for seed in range(100, 100 + N):
-    fs = rich_scene(9000 + seed) if MODE == "rich" else _random_scene(5000 + seed)
+def far_and_scaled(fs, seed):
+    """The same scene moved far from the origin and / or scaled by orders of magnitude (camera and lights with it): the
+    conservative box tests of the walks have to hold where f32 spacing is 1e-3 and where whole meshes are 1e-3 wide."""
+    rng = np.random.default_rng(seed + 77)
+    s = float(rng.choice([0.25, 1.0, 10.0, 1e2, 1e3, 1e4]))   # (rays start on the z = -1 view plane: far smaller scenes are clipped away)
+    off = rng.uniform(-1.0, 1.0, 3) * float(rng.choice([0.0, 10.0, 1e2, 1e3, 1e4])) * s
+    S = np.diag([s, s, s, 1.0]); T = np.eye(4); T[:3, 3] = off
+    M = T @ S
+    for it in fs.items:
+        t = (M @ np.asarray(it.trans, np.float64)).astype(np.float32)
+        it.trans = t
+        it.trans_inv = np.linalg.inv(t.astype(np.float64)).astype(np.float32)
+    for l in fs.lights:
+        l.pos = tuple((np.asarray(l.pos, np.float64) * s + off).tolist())
+        if l.light_type != 0:
+            l.intensity = float(l.intensity) * s          # I / (4 pi d): keeps the picture
+    c = fs.meta["camera"]
+    c["eye_pos"] = [float(np.float32(v)) for v in (np.asarray(c["eye_pos"], np.float64) * s + off)]
+    c["clipping_near"], c["clipping_far"] = 0.1 * s, 100.0 * s
+    return fs, s
+
+
+def case(seed, mode):
+    """The scene, frame size, config keywords and oracle mode of one fuzz seed."""
+    fs = rich_scene(9000 + seed) if mode in ("rich", "far") else _random_scene(5000 + seed)
+    scale = 1.0
+    if mode in ("far", "farbasic"):
+        fs, scale = far_and_scaled(fs, seed)
     rng = np.random.default_rng(seed)
     w, h = int(rng.integers(40, 110)), int(rng.integers(30, 90))
-    cam = camera_for(fs, w, h).c_struct()
-    cfg = make_config(samples=int(rng.choice([1, 2, 3, 4, 6, 16, 64])), monte_carlo=bool(seed % 3), seed=seed, max_recursion=int(rng.choice([1, 2, 4, 6, 9])),
-                      fog_density=float(rng.choice([0.0, 0.02])), gamma_correction=bool(seed % 5 == 0),
-                      aperture_size=float(rng.choice([1.0, 1.0, 8.0])), focal_length=float(rng.choice([1.0, 6.0])))
-    with capi.DeviceScene(fs, 0) as ds:
-        if seed % 4 == 0:
-            ds.set_tuning(bin_min_rays=1)
-        if seed % 7 == 0 and MODE != "rich":
-            ds.set_tuning(queue_budget_bytes=1, shade_chunk_rays=65536)
-        out = ds.render(cam, cfg)
-        st = ds.stats()
-    ref = ob.render(fs.c_struct(), cam, cfg, n_threads=14, want_counters=True)
-    r = compare_frames(out, ref)
-    c = ref["counters"]
-    pixels_ok = r["n_rgb_over"] == 0 and r["n_id_diff"] == 0 and r["nan_mismatch"] == 0 and r["max_depth_rel"] < 1e-4
-    tree_ok = (st["primary_rays"] == c["rays_primary"] and st["secondary_rays"] == c["rays_secondary"] and st["shaded_hits"] == c["shaded_hits"]
-               and st["shadow_rays"] <= c["rays_shadow"])
-    if pixels_ok and not tree_ok:
-        tree_only = globals().get("tree_only", 0) + 1   # a NaN ray (normalised zero vector) may be pruned by one walk and "hit" with toi = NaN in the other: the pixel is NaN either way
-    ok = pixels_ok
-    if not ok:
-        bad += 1
-        if len(sys.argv) > 3: continue
-        print("MISMATCH seed", seed, r, {k: st[k] for k in ("primary_rays", "secondary_rays", "shaded_hits", "shadow_rays")}, {k: c[k] for k in ("rays_primary", "rays_secondary", "shaded_hits", "rays_shadow")})
-print(f"{N} random scenes, {bad} pixel mismatches, {globals().get('tree_only', 0)} with equal pixels but different ray counts, {time.time() - t0:.0f} s")
+    kw = dict(samples=int(rng.choice([1, 2, 3, 4, 6, 16, 64])), monte_carlo=bool(seed % 3), seed=seed, max_recursion=int(rng.choice([1, 2, 4, 6, 9])),
+              fog_density=float(rng.choice([0.0, 0.02])), gamma_correction=bool(seed % 5 == 0),
+              aperture_size=float(rng.choice([1.0, 1.0, 8.0])), focal_length=float(rng.choice([1.0, 6.0])))
+    brute = mode in ("far", "farbasic") and seed % 2 == 0
+    return fs, w, h, kw, brute, scale
+
+
+def depth_ok(a, b):
+    """Depth sums are fixed point with 2^-16 resolution; NaN and infinite depths must sit in the same pixels."""
+    da, db = a.astype(np.float64), b.astype(np.float64)
+    fin = np.isfinite(da) & np.isfinite(db)
+    return bool(np.array_equal(np.isnan(da), np.isnan(db)) and np.all(np.abs(da - db)[fin] <= 1e-5 * np.abs(db[fin]) + 2e-5)
+                and np.array_equal(da[~fin & ~np.isnan(da)], db[~fin & ~np.isnan(db)]))
+
+
+def main():
+    mode = sys.argv[2] if len(sys.argv) > 2 else "basic"
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    bad = tree_only = 0
+    t0 = time.time()
+    for seed in range(100, 100 + n):
+        fs, w, h, kw, brute, _ = case(seed, mode)
+        cam = camera_for(fs, w, h).c_struct()
+        cfg = make_config(**kw)
+        with capi.DeviceScene(fs, 0) as ds:
+            if seed % 4 == 0:
+                ds.set_tuning(bin_min_rays=1)
+            if seed % 7 == 0 and mode != "rich":
+                ds.set_tuning(queue_budget_bytes=1, shade_chunk_rays=65536)
+            out = ds.render(cam, cfg)
+            st = ds.stats()
+        ref = ob.render(fs.c_struct(), cam, cfg, n_threads=14, want_counters=True, brute_force=brute)
+        r = compare_frames(out, ref)
+        c = ref["counters"]
+        pixels_ok = r["n_rgb_over"] == 0 and r["n_id_diff"] == 0 and r["nan_mismatch"] == 0 and depth_ok(out["depth"], ref["depth"])
+        tree_ok = (st["primary_rays"] == c["rays_primary"] and st["secondary_rays"] == c["rays_secondary"] and st["shaded_hits"] == c["shaded_hits"]
+                   and st["shadow_rays"] <= c["rays_shadow"])
+        if pixels_ok and not tree_ok:
+            tree_only += 1
+            print("RAY COUNTS seed", seed, {k: st[k] for k in ("primary_rays", "secondary_rays", "shaded_hits", "shadow_rays")}, {k: c[k] for k in ("rays_primary", "rays_secondary", "shaded_hits", "rays_shadow")})
+        if not pixels_ok:
+            bad += 1
+            print("MISMATCH seed", seed, r, {k: st[k] for k in ("primary_rays", "secondary_rays", "shaded_hits", "shadow_rays")}, {k: c[k] for k in ("rays_primary", "rays_secondary", "shaded_hits", "rays_shadow")})
+    print(f"{n} random scenes ({mode}), {bad} pixel mismatches, {tree_only} with equal pixels but different ray counts, {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
