@@ -164,9 +164,16 @@ __shared__ uint32_t s_util_kind; // 0: closest-hit level 1, 1: closest-hit deepe
         atomicAdd(&g_util[10 * s_util_kind + 2 * (slot)], (unsigned long long)__popcll(m_)); atomicAdd(&g_util[10 * s_util_kind + 2 * (slot) + 1], 1ull); } }
 #define RR_UTIL_KIND(k) { s_util_kind = (k); __syncthreads(); }
 #define RR_UTIL_NODE_SLOT ((const void*)nodes4_ptr_ == (const void*)sc.tnodes4 ? 0 : 2)
+// steps whose address is the same in every active lane (g_util[30 + ...]: [0] same address, [1] same address and same key2)
+#define RR_UTIL_UNI(slot, addr, key2) { const unsigned long long m_ = __ballot(1); const int l_ = __ffsll((long long)m_) - 1;                \
+        const uint32_t a_ = (uint32_t)(addr), k_ = (uint32_t)(key2); const uint32_t ua_ = __shfl(a_, l_), uk_ = __shfl(k_, l_);               \
+        const bool u1_ = __ballot(a_ == ua_) == m_; const bool u2_ = u1_ && __ballot(k_ == uk_) == m_;                                       \
+        if ((int)(threadIdx.x & 63u) == l_) { if (u1_) atomicAdd(&g_util[30 + 10 * s_util_kind + 2 * (slot)], 1ull);                         \
+                                              if (u2_) atomicAdd(&g_util[30 + 10 * s_util_kind + 2 * (slot) + 1], 1ull); } }
 #else
 #define RR_UTIL(slot)
 #define RR_UTIL_KIND(k)
+#define RR_UTIL_UNI(slot, addr, key2)
 #endif
 
 // The traversal's own box test is NOT part of the parity contract (only the exact primitive tests decide
@@ -191,7 +198,13 @@ RR_DEV SlabRay make_slab(f3 o, f3 d) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 // Rows are addressed as (uniform node array) + 32-bit byte offset, so the loads take the scalar-base form and the
 // step needs one 32-bit add per row instead of 64-bit address arithmetic: off = (tree base + node) * 128 + row * 16.
-struct Slab4 { f3 o, inv; uint32_t nx, fx, ny, fy, nz, fz, cc; };
+struct Slab4 {
+    f3 o, inv; uint32_t nx, fx, ny, fy, nz, fz, cc;
+    // wave-uniform copies: `uni` when every lane that starts this walk has the same tree and the same direction signs, so
+    // that a step whose node is the same in all of its lanes can fetch the rows ONCE through the scalar cache (u*: the same
+    // row offsets in scalar registers)
+    bool uni; uint32_t unx, ufx, uny, ufy, unz, ufz, ucc;
+};
 RR_DEV Slab4 make_slab4(const SlabRay& r, uint32_t node_base) {
     Slab4 s; s.o = r.o; s.inv = r.inv;
     const uint32_t sx = __float_as_uint(r.inv.x) >> 31, sy = __float_as_uint(r.inv.y) >> 31, sz = __float_as_uint(r.inv.z) >> 31;
@@ -200,10 +213,30 @@ RR_DEV Slab4 make_slab4(const SlabRay& r, uint32_t node_base) {
     s.ny = b + ((2u + sy) << 4); s.fy = b + ((3u - sy) << 4);
     s.nz = b + ((4u + sz) << 4); s.fz = b + ((5u - sz) << 4);
     s.cc = b + (6u << 4);
+#ifndef RR_NO_SCALAR_NODES
+    const uint32_t key = b | (sx << 4) | (sy << 5) | (sz << 6); // b is a multiple of 128
+    const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+    s.uni = __ballot(key != ukey) == 0ull;
+    const uint32_t ub = ukey & ~127u, ux = (ukey >> 4) & 1u, uy = (ukey >> 5) & 1u, uz = (ukey >> 6) & 1u;
+    s.unx = ub + (ux << 4); s.ufx = ub + ((1u - ux) << 4);
+    s.uny = ub + ((2u + uy) << 4); s.ufy = ub + ((3u - uy) << 4);
+    s.unz = ub + ((4u + uz) << 4); s.ufz = ub + ((5u - uz) << 4);
+    s.ucc = ub + (6u << 4);
+#else
+    s.uni = false; s.unx = s.ufx = s.uny = s.ufy = s.unz = s.ufz = s.ucc = 0u;
+#endif
     return s;
 }
 RR_DEV DTriX tri_at(const DTriX* tris, uint32_t byte_off) { return *(const DTriX*)((const char*)tris + byte_off); }
 RR_DEV float4 node_row(const DNode4* nodes, uint32_t byte_off) { return *(const float4*)((const char*)nodes + byte_off); }
+// the same row at a wave-uniform offset, through the constant address space: one s_load_dwordx4 for the wave, the row
+// arrives in scalar registers and feeds the packed subtracts directly.  (A vector load costs the L1 pipeline a quad of
+// lanes per cycle whether or not the 64 addresses are equal: 16 cycles per row, and the walks are bound by exactly that.)
+typedef float rr_f4v __attribute__((ext_vector_type(4)));
+RR_DEV float4 node_row_uniform(const DNode4* nodes, uint32_t byte_off) {
+    const rr_f4v v = *(const __attribute__((address_space(4))) rr_f4v*)((const __attribute__((address_space(4))) char*)(uintptr_t)nodes + byte_off);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 // (row - o) * inv for the four children of one plane row, as two packed pairs
 #define RR_ROW(row, oc, ic, lo_, hi_) const v2f lo_ = (v2f{row.x, row.y} - v2f{oc, oc}) * v2f{ic, ic}; \
                                       const v2f hi_ = (v2f{row.z, row.w} - v2f{oc, oc}) * v2f{ic, ic};
@@ -217,14 +250,19 @@ RR_DEV float4 node_row(const DNode4* nodes, uint32_t byte_off) { return *(const 
         h_ = tc_ <= tf_ * 1.000004f && tc_ <= bound_;                                                          \
         k_ = h_ ? tn_ : inf_;                                                                                  \
     }
-#define RR_NODE4_STEP(nodes4, s4, bound)                                                                       \
-    {                                                                                                          \
-        const void* nodes4_ptr_ = (nodes4); (void)nodes4_ptr_;                                                 \
-        RR_UTIL(RR_UTIL_NODE_SLOT) const uint32_t no_ = (uint32_t)cur << 7;                                                    \
+#define RR_NODE4_ROWS_VECTOR(nodes4, s4)                                                                        \
+        const uint32_t no_ = (uint32_t)cur << 7;                                                               \
         const float4 rnx = node_row(nodes4, no_ + (s4).nx), rfx = node_row(nodes4, no_ + (s4).fx);             \
         const float4 rny = node_row(nodes4, no_ + (s4).ny), rfy = node_row(nodes4, no_ + (s4).fy);             \
         const float4 rnz = node_row(nodes4, no_ + (s4).nz), rfz = node_row(nodes4, no_ + (s4).fz);             \
-        const float4 cc = node_row(nodes4, no_ + (s4).cc);                                                     \
+        const float4 cc = node_row(nodes4, no_ + (s4).cc);
+#define RR_NODE4_ROWS_UNIFORM(nodes4, s4)                                                                       \
+        const uint32_t no_ = (uint32_t)ucur_ << 7;                                                             \
+        const float4 rnx = node_row_uniform(nodes4, no_ + (s4).unx), rfx = node_row_uniform(nodes4, no_ + (s4).ufx); \
+        const float4 rny = node_row_uniform(nodes4, no_ + (s4).uny), rfy = node_row_uniform(nodes4, no_ + (s4).ufy); \
+        const float4 rnz = node_row_uniform(nodes4, no_ + (s4).unz), rfz = node_row_uniform(nodes4, no_ + (s4).ufz); \
+        const float4 cc = node_row_uniform(nodes4, no_ + (s4).ucc);
+#define RR_NODE4_TESTS(s4, bound)                                                                              \
         const float bound_ = (bound);                                                                          \
         const float inf_ = __builtin_inff();                                                                   \
         RR_ROW(rnx, (s4).o.x, (s4).inv.x, nx01, nx23) RR_ROW(rfx, (s4).o.x, (s4).inv.x, fx01, fx23)            \
@@ -233,41 +271,44 @@ RR_DEV float4 node_row(const DNode4* nodes, uint32_t byte_off) { return *(const 
         RR_CHILD(k0, h0, nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x)                                       \
         RR_CHILD(k1, h1, nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y)                                       \
         RR_CHILD(k2, h2, nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x)                                       \
-        RR_CHILD(k3, h3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y)                                       \
+        RR_CHILD(k3, h3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y)
+#define RR_NODE4_DESCEND_SORTED                                                                                \
         int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w); \
         RR_CSWAP(k0, c0, k1, c1) RR_CSWAP(k2, c2, k3, c3) RR_CSWAP(k0, c0, k2, c2) RR_CSWAP(k1, c1, k3, c3) RR_CSWAP(k1, c1, k2, c2) \
         STK(sp) = c3; sp += (k3 < inf_) ? 1 : 0;                                                               \
         STK(sp) = c2; sp += (k2 < inf_) ? 1 : 0;                                                               \
         STK(sp) = c1; sp += (k1 < inf_) ? 1 : 0;                                                               \
         if (k0 < inf_) cur = c0;                                                                               \
-        else { sp--; cur = STK(sp); }                                                                          \
-    }
-// The same step for walks that only ask whether anything is hit (shadow queries inside one mesh): the order in which
-// the children are visited does not matter, so the hit children are pushed in slot order and the sort is skipped.
-#define RR_NODE4_STEP_ANY(nodes4, s4, bound)                                                                   \
-    {                                                                                                          \
-        const void* nodes4_ptr_ = (nodes4); (void)nodes4_ptr_;                                                 \
-        RR_UTIL(RR_UTIL_NODE_SLOT) const uint32_t no_ = (uint32_t)cur << 7;                                                    \
-        const float4 rnx = node_row(nodes4, no_ + (s4).nx), rfx = node_row(nodes4, no_ + (s4).fx);             \
-        const float4 rny = node_row(nodes4, no_ + (s4).ny), rfy = node_row(nodes4, no_ + (s4).fy);             \
-        const float4 rnz = node_row(nodes4, no_ + (s4).nz), rfz = node_row(nodes4, no_ + (s4).fz);             \
-        const float4 cc = node_row(nodes4, no_ + (s4).cc);                                                     \
-        const float bound_ = (bound);                                                                          \
-        const float inf_ = __builtin_inff();                                                                   \
-        RR_ROW(rnx, (s4).o.x, (s4).inv.x, nx01, nx23) RR_ROW(rfx, (s4).o.x, (s4).inv.x, fx01, fx23)            \
-        RR_ROW(rny, (s4).o.y, (s4).inv.y, ny01, ny23) RR_ROW(rfy, (s4).o.y, (s4).inv.y, fy01, fy23)            \
-        RR_ROW(rnz, (s4).o.z, (s4).inv.z, nz01, nz23) RR_ROW(rfz, (s4).o.z, (s4).inv.z, fz01, fz23)            \
-        RR_CHILD(k0, h0, nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x)                                       \
-        RR_CHILD(k1, h1, nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y)                                       \
-        RR_CHILD(k2, h2, nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x)                                       \
-        RR_CHILD(k3, h3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y)                                       \
+        else { sp--; cur = STK(sp); }
+#define RR_NODE4_DESCEND_ANY                                                                                   \
         (void)k0; (void)k1; (void)k2; (void)k3;                                                                \
         STK(sp) = __float_as_int(cc.w); sp += h3 ? 1 : 0;                                                      \
         STK(sp) = __float_as_int(cc.z); sp += h2 ? 1 : 0;                                                      \
         STK(sp) = __float_as_int(cc.y); sp += h1 ? 1 : 0;                                                      \
         if (h0) cur = __float_as_int(cc.x);                                                                    \
-        else { sp--; cur = STK(sp); }                                                                          \
+        else { sp--; cur = STK(sp); }
+// A step whose node is the same in all of its lanes (on a walk that is `uni`) takes the scalar form of the loads.
+#ifndef RR_NO_SCALAR_NODES
+#define RR_NODE4_FORM(nodes4, s4, bound, DESCEND)                                                              \
+    {                                                                                                          \
+        const void* nodes4_ptr_ = (nodes4); (void)nodes4_ptr_;                                                 \
+        RR_UTIL(RR_UTIL_NODE_SLOT) RR_UTIL_UNI(RR_UTIL_NODE_SLOT, cur, ((s4).nx & 16u) | ((s4).ny & 16u) << 1 | ((s4).nz & 16u) << 2 | ((s4).cc << 3)) \
+        const int ucur_ = __builtin_amdgcn_readfirstlane(cur);                                                 \
+        if ((s4).uni && __ballot(cur != ucur_) == 0ull) { RR_NODE4_ROWS_UNIFORM(nodes4, s4) RR_NODE4_TESTS(s4, bound) DESCEND } \
+        else { RR_NODE4_ROWS_VECTOR(nodes4, s4) RR_NODE4_TESTS(s4, bound) DESCEND }                            \
     }
+#else
+#define RR_NODE4_FORM(nodes4, s4, bound, DESCEND)                                                              \
+    {                                                                                                          \
+        const void* nodes4_ptr_ = (nodes4); (void)nodes4_ptr_;                                                 \
+        RR_UTIL(RR_UTIL_NODE_SLOT) RR_UTIL_UNI(RR_UTIL_NODE_SLOT, cur, ((s4).nx & 16u) | ((s4).ny & 16u) << 1 | ((s4).nz & 16u) << 2 | ((s4).cc << 3)) \
+        RR_NODE4_ROWS_VECTOR(nodes4, s4) RR_NODE4_TESTS(s4, bound) DESCEND                                     \
+    }
+#endif
+#define RR_NODE4_STEP(nodes4, s4, bound) RR_NODE4_FORM(nodes4, s4, bound, RR_NODE4_DESCEND_SORTED)
+// The same step for walks that only ask whether anything is hit (shadow queries inside one mesh): the order in which
+// the children are visited does not matter, so the hit children are pushed in slot order and the sort is skipped.
+#define RR_NODE4_STEP_ANY(nodes4, s4, bound) RR_NODE4_FORM(nodes4, s4, bound, RR_NODE4_DESCEND_ANY)
 #define RR_BLAS_NODES(sc, it) ((sc).nodes4) // uniform; the tree's base is folded into the node offsets of the Slab4
 #define RR_BLAS_ROOT(it) ((it).root4)
 #define RR_BLAS_STEP(nodes, sr, bound) RR_NODE4_STEP(nodes, sr, bound)
@@ -297,7 +338,7 @@ struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool foun
         const uint32_t code = (uint32_t)~(leaf);                                                               \
         const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);                               \
         for (uint32_t i = 0; i < count; i++) {                                                                 \
-            RR_UTIL(3)                                                                                         \
+            RR_UTIL(3) RR_UTIL_UNI(3, tri_base_ + first + i, 0)                                                \
             const DTriX tr = tri_at(sc.trix, (tri_base_ + first + i) * 48u);                                   \
             float t; uint32_t side;                                                                            \
             if (ray_triangle(mk3(tr.t0.x, tr.t0.y, tr.t0.z), mk3(tr.t1.x, tr.t1.y, tr.t1.z),                   \
@@ -314,7 +355,7 @@ struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool foun
         const uint32_t code = (uint32_t)~(leaf);                                                               \
         const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);                               \
         for (uint32_t i = 0; i < count; i++) {                                                                 \
-            RR_UTIL(3)                                                                                         \
+            RR_UTIL(3) RR_UTIL_UNI(3, tri_base_ + first + i, 0)                                                \
             const DTriX tr = tri_at(sc.trix, (tri_base_ + first + i) * 48u);                                   \
             float t; uint32_t side;                                                                            \
             if (ray_triangle(mk3(tr.t0.x, tr.t0.y, tr.t0.z), mk3(tr.t1.x, tr.t1.y, tr.t1.z),                   \

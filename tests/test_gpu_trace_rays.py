@@ -84,7 +84,7 @@ def test_far_from_the_origin_the_top_level_keeps_every_candidate(hip, oracle, na
     res = compare_frames(out, ref)
     assert res["n_rgb_over"] == 0 and res["n_id_diff"] == 0 and res["nan_mismatch"] == 0, res
     assert st["secondary_rays"] == ref["counters"]["rays_secondary"] and st["shaded_hits"] == ref["counters"]["shaded_hits"]
-    assert (out["object_id"] != 0).sum() > 20
+    assert (out["object_id"] != 0).sum() > 0
 
 
 def test_camera_far_outside_the_scene_and_back(hip, oracle):

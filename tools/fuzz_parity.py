@@ -171,10 +171,16 @@ def main():
                 ds.set_tuning(queue_budget_bytes=1, shade_chunk_rays=65536)
             out = ds.render(cam, cfg)
             st = ds.stats()
-        ref = ob.render(fs.c_struct(), cam, cfg, n_threads=14, want_counters=True, brute_force=brute)
-        r = compare_frames(out, ref)
-        c = ref["counters"]
-        pixels_ok = r["n_rgb_over"] == 0 and r["n_id_diff"] == 0 and r["nan_mismatch"] == 0 and depth_ok(out["depth"], ref["depth"])
+        def check(brute_force):
+            ref = ob.render(fs.c_struct(), cam, cfg, n_threads=14, want_counters=True, brute_force=brute_force)
+            r = compare_frames(out, ref)
+            return r, ref["counters"], r["n_rgb_over"] == 0 and r["n_id_diff"] == 0 and r["nan_mismatch"] == 0 and depth_ok(out["depth"], ref["depth"])
+        r, c, pixels_ok = check(brute)
+        if not pixels_ok and not brute and mode in ("far", "farbasic"):
+            # the oracle's own item tree stands in for the `bvh` crate's (absent dependency) and tests unpadded f32 boxes: where float
+            # spacing is a thousandth of the scene it drops candidates the item-space test accepts.  The all-items form decides.
+            r, c, pixels_ok = check(True)
+            print("NOTE seed", seed, "differs from the oracle's item-tree form only" if pixels_ok else "differs from both oracle forms")
         tree_ok = (st["primary_rays"] == c["rays_primary"] and st["secondary_rays"] == c["rays_secondary"] and st["shaded_hits"] == c["shaded_hits"]
                    and st["shadow_rays"] <= c["rays_shadow"])
         if pixels_ok and not tree_ok:
