@@ -90,6 +90,8 @@ struct rr_scene {
     uint32_t n_materials = 0;
     uint32_t n_enabled_lights = 0;
     uint32_t tlas_node_capacity = 0;
+    std::vector<float4> h_item_boxes; // padded world boxes per item (lo, hi), filled by build_tlas
+    DevBuf item_boxes;
     double tlas_reach[3] = {0.0, 0.0, 0.0}; // the top level's boxes are padded for ray origins within +-tlas_reach (build_tlas)
     double tlas_floor[3] = {0.0, 0.0, 0.0}; // ... and never for less than this: the items' own extent
     int tlas_depth_limit = RR_TLAS_MAX_DEPTH, blas_depth_limit = RR_BLAS_MAX_DEPTH; // shares of the traversal stack, see rr_scene_create
@@ -433,6 +435,11 @@ static int build_tlas(rr_scene* s, const double want_reach[3], std::vector<DNode
     }
     std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
     for (uint32_t i = 0; i < n; i++) padded_world_box(s->h_items[i], exact[i], s->tlas_reach, &lo[3 * (size_t)i], &hi[3 * (size_t)i]);
+    s->h_item_boxes.resize(2 * (size_t)n);
+    for (uint32_t i = 0; i < n; i++) {
+        s->h_item_boxes[2 * (size_t)i] = make_float4(lo[3 * (size_t)i], lo[3 * (size_t)i + 1], lo[3 * (size_t)i + 2], 0.0f);
+        s->h_item_boxes[2 * (size_t)i + 1] = make_float4(hi[3 * (size_t)i], hi[3 * (size_t)i + 1], hi[3 * (size_t)i + 2], 0.0f);
+    }
     rr::BvhResult r;
     if (!rr::build_bvh(lo.data(), hi.data(), n, 1, s->tlas_depth_limit, &r))
         return fail(RR_ERR_UNSUPPORTED, "scene has too many items (%u) for the top-level depth limit", n);
@@ -470,6 +477,7 @@ static int ensure_tlas_reach(rr_scene* s, const double need[3]) {
         return fail(RR_ERR_DEVICE, "top-level rebuild needs %zu nodes, capacity %u", tlas4.size(), s->tlas_node_capacity);
     HIP_TRY(hipDeviceSynchronize());
     if (!tlas4.empty()) HIP_TRY(hipMemcpy(s->tnodes4.p, tlas4.data(), tlas4.size() * sizeof(DNode4), hipMemcpyHostToDevice));
+    if (!s->h_item_boxes.empty()) HIP_TRY(hipMemcpy(s->item_boxes.p, s->h_item_boxes.data(), s->h_item_boxes.size() * sizeof(float4), hipMemcpyHostToDevice));
     s->view.tlas_root4 = root4;
     return RR_OK;
 }
@@ -677,6 +685,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     HIP_TRY(upload(s->nodes4, all_nodes4.data(), all_nodes4.size() * sizeof(DNode4)));
     tlas4.resize(std::max<size_t>(tlas4.size(), s->tlas_node_capacity));
     HIP_TRY(upload(s->tnodes4, tlas4.data(), tlas4.size() * sizeof(DNode4)));
+    HIP_TRY(upload(s->item_boxes, s->h_item_boxes.data(), s->h_item_boxes.size() * sizeof(float4)));
     HIP_TRY(upload(s->tris, all_tris.data(), all_tris.size() * sizeof(DTri)));
     if (all_trix.size() >= (1u << 26)) return fail(RR_ERR_UNSUPPORTED, "%zu triangles (addressed with 32-bit byte offsets)", all_trix.size());
     static_assert(sizeof(DTriX) == 48 && sizeof(DNode4) == 128, "layouts the kernels address by byte offset");
@@ -691,6 +700,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     v.materials = s->materials.as<DMaterial>(); v.textures = s->textures.as<DTexture>(); v.texels = s->texels.as<uint32_t>();
     v.lights = s->lights.as<DLight>();
     v.n_items = fs->n_items; v.n_lights = fs->n_lights;
+    v.item_boxes = s->item_boxes.as<float4>();
     v.tnodes4 = s->tnodes4.as<DNode4>(); v.tlas_root4 = tlas_root4; v.general_w = general_w ? 1u : 0u;
 
     HIP_TRY(s->pool.reserve(POOL_WORDS * 4));
@@ -734,6 +744,7 @@ extern "C" int rr_scene_update_transforms(rr_scene* s, const float* trans, const
         if (tlas4.size() > s->tlas_node_capacity)
             return fail(RR_ERR_DEVICE, "top-level rebuild needs %zu nodes, capacity %u", tlas4.size(), s->tlas_node_capacity);
         if (!tlas4.empty()) HIP_TRY(hipMemcpy(s->tnodes4.p, tlas4.data(), tlas4.size() * sizeof(DNode4), hipMemcpyHostToDevice));
+        if (!s->h_item_boxes.empty()) HIP_TRY(hipMemcpy(s->item_boxes.p, s->h_item_boxes.data(), s->h_item_boxes.size() * sizeof(float4), hipMemcpyHostToDevice));
         s->view.tlas_root4 = root4;
     }
     return RR_OK;

@@ -118,6 +118,7 @@ struct DSceneView {
     uint32_t n_lights;
     const DNode4* tnodes4;  // the top level over item world boxes, same form (one item per leaf)
     int32_t tlas_root4;      // node index, a leaf code (one item), or RR_SENTINEL (empty scene)
+    const float4* item_boxes; // the same padded world boxes per item: [2 i] = lo, [2 i + 1] = hi (the packet form of the top level, trace_closest_packet)
     uint32_t any_alpha_occluder; // some item's material has an alpha map: its shadow attenuation can be NaN (k_shade, want_shadow)
     uint32_t general_w;      // some trans_inv has a w row other than (0,0,0,1)
 };
