@@ -92,6 +92,7 @@ struct rr_scene {
     uint32_t tlas_node_capacity = 0;
     std::vector<float4> h_item_boxes; // padded world boxes per item (lo, hi), filled by build_tlas
     DevBuf item_boxes;
+    DevBuf sq_valid; // one 64-bit word per (enabled light, 64 shadow slots): which lanes hold a ray
     double tlas_reach[3] = {0.0, 0.0, 0.0}; // the top level's boxes are padded for ray origins within +-tlas_reach (build_tlas)
     double tlas_floor[3] = {0.0, 0.0, 0.0}; // ... and never for less than this: the items' own extent
     int tlas_depth_limit = RR_TLAS_MAX_DEPTH, blas_depth_limit = RR_BLAS_MAX_DEPTH; // shares of the traversal stack, see rr_scene_create
@@ -550,6 +551,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         dl[i].intensity = l.intensity; dl[i].max_angle = l.max_angle;
         dl[i].type = l.light_type | (l.enabled ? 0u : 0x80u);
         if (l.enabled) s->n_enabled_lights++;
+        if (s->n_enabled_lights > 32u) return fail(RR_ERR_UNSUPPORTED, "more than 32 enabled lights");
     }
     HIP_TRY(s->lights.reserve(std::max<size_t>(dl.size(), 1) * sizeof(DLight)));
     if (!dl.empty()) HIP_TRY(hipMemcpy(s->lights.p, dl.data(), dl.size() * sizeof(DLight), hipMemcpyHostToDevice));
@@ -699,7 +701,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     v.face_slot = s->face_slot.as<uint32_t>();
     v.materials = s->materials.as<DMaterial>(); v.textures = s->textures.as<DTexture>(); v.texels = s->texels.as<uint32_t>();
     v.lights = s->lights.as<DLight>();
-    v.n_items = fs->n_items; v.n_lights = fs->n_lights;
+    v.n_items = fs->n_items; v.n_lights = fs->n_lights; v.n_enabled_lights = s->n_enabled_lights;
     v.item_boxes = s->item_boxes.as<float4>();
     v.tnodes4 = s->tnodes4.as<DNode4>(); v.tlas_root4 = tlas_root4; v.general_w = general_w ? 1u : 0u;
 
@@ -976,9 +978,12 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     }
     HIP_TRY(s->hit1.reserve(B * 16));
     const uint64_t chunk = s->tuning.shade_chunk_rays ? std::max<uint64_t>(65536, s->tuning.shade_chunk_rays) : (64ull << 20);
-    const uint64_t sq_need = std::max<uint64_t>(1, (std::min<uint64_t>(chunk, M) + RR_BLOCK * RR_SQ_SHARDS) * std::max<uint32_t>(s->n_enabled_lights, 1u));
+    // level 1: fixed shadow slots, (enabled light, hit of the chunk), the chunk padded to whole workgroup iterations;
+    // deeper levels: the dense sharded queue (a shard's static share of the chunk, one slack group per shard)
+    const uint64_t sq_need = std::max<uint64_t>(1, (std::min<uint64_t>(chunk, std::max<uint64_t>(M, B)) + RR_BLOCK * RR_SQ_SHARDS) * std::max<uint32_t>(s->n_enabled_lights, 1u));
     if (sq_need > s->sq_cap) {
         for (int k = 0; k < 3; k++) HIP_TRY(s->sq[k].reserve(sq_need * 16));
+        HIP_TRY(s->sq_valid.reserve((sq_need / RR_WAVE + 1) * 8));
         s->sq_cap = sq_need;
     }
     auto queue_at = [&](uint64_t base) {
@@ -1050,7 +1055,12 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
                 if (cancel && *cancel) { (void)hipStreamSynchronize(st); return fail(RR_ERR_CANCELLED, "cancelled"); }
                 const uint64_t c1 = std::min<uint64_t>(c0 + chunk, s1);
                 const int grid = (int)std::min<uint64_t>((c1 - c0 + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)shade_grid_max);
-                // shadow sub-queues: a shard gets the packets with (packet % RR_SQ_SHARDS == shard), L rays per hit at most
+                // level 1: shadow slots of this chunk = L x (the chunk padded to whole workgroup iterations), one validity word per 64
+                // (only where the shadow kernel's packet form applies: rr_kernels.hip, RR_BEAM_MIN_ITEMS .. RR_BEAM_MAX_ITEMS)
+                const bool sq_fixed = d == 1 && s->view.n_items >= RR_BEAM_MIN_ITEMS && s->view.n_items <= RR_BEAM_MAX_ITEMS;
+                const uint32_t sq_chunk_cap = sq_fixed ? (uint32_t)(((c1 - c0 + RR_BLOCK - 1) / RR_BLOCK) * RR_BLOCK) : 0u;
+                unsigned long long* sq_valid = s->sq_valid.as<unsigned long long>();
+                // deeper levels: shadow sub-queues, a shard gets the packets with (packet % RR_SQ_SHARDS == shard), L rays per hit at most
                 const uint64_t groups = (c1 - c0 + RR_BLOCK - 1) / RR_BLOCK; // 256-ray groups, dealt round-robin to the shards
                 const uint32_t segcap = (uint32_t)(((groups + RR_SQ_SHARDS - 1) / RR_SQ_SHARDS) * RR_BLOCK * std::max(L, 1u));
                 next_word = (next_word + 31u) & ~31u; // the append counters start on a 128-B line
@@ -1060,9 +1070,9 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
                 {
                     ScopedTimer t(s, st, 2);
                     if (d == 1) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(RR_BLOCK), 0, st, s->shade_const.as<DShadeConst>(), s->region_xy.as<uint32_t>(), pr, qin, count,
-                                                   (uint32_t)c0, (uint32_t)c1, qout, child_count, SQ, sq_counts, segcap, acc, counters);
+                                                   (uint32_t)c0, (uint32_t)c1, qout, child_count, SQ, sq_counts, segcap, sq_valid, sq_chunk_cap, acc, counters);
                     else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(RR_BLOCK), 0, st, s->shade_const.as<DShadeConst>(), s->region_xy.as<uint32_t>(), pr, qin, count,
-                                            (uint32_t)c0, (uint32_t)c1, qout, child_count, SQ, sq_counts, segcap, acc, counters);
+                                            (uint32_t)c0, (uint32_t)c1, qout, child_count, SQ, sq_counts, segcap, sq_valid, sq_chunk_cap, acc, counters);
                 }
                 // The size of the next level is final once the slice's last shade chunk has run: its read-back is enqueued
                 // BEFORE that chunk's shadow kernel, so the host learns it (and enqueues the next level) while the shadow
@@ -1073,9 +1083,15 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
                 }
                 if (L) {
                     ScopedTimer t(s, st, 1);
-                    const uint64_t sq_ub = (c1 - c0) * L;
-                    const int sgrid = (int)std::min<uint64_t>((sq_ub + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)trace_grid);
-                    hipLaunchKernelGGL(k_trace_shadow, dim3(sgrid), dim3(RR_BLOCK), 0, st, s->view, SQ, sq_counts, segcap, shead, acc);
+                    if (sq_fixed) {
+                        const uint32_t sq_packets = (sq_chunk_cap / RR_WAVE) * L;
+                        const int sgrid = (int)std::min<uint64_t>(((uint64_t)sq_packets * RR_WAVE + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)trace_grid);
+                        hipLaunchKernelGGL(k_trace_shadow<true>, dim3(sgrid), dim3(RR_BLOCK), 0, st, s->view, SQ, sq_counts, segcap, sq_valid, sq_packets, shead, acc);
+                    } else {
+                        const uint64_t sq_ub = (c1 - c0) * L;
+                        const int sgrid = (int)std::min<uint64_t>((sq_ub + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)trace_grid);
+                        hipLaunchKernelGGL(k_trace_shadow<false>, dim3(sgrid), dim3(RR_BLOCK), 0, st, s->view, SQ, sq_counts, segcap, sq_valid, 0u, shead, acc);
+                    }
                 }
             }
             if (!spawns) continue;

@@ -116,6 +116,7 @@ struct DSceneView {
     const DLight* lights;
     uint32_t n_items;
     uint32_t n_lights;
+    uint32_t n_enabled_lights; // <= 32: one bit per enabled light in k_shade's per-lane "wrote a shadow ray" word
     const DNode4* tnodes4;  // the top level over item world boxes, same form (one item per leaf)
     int32_t tlas_root4;      // node index, a leaf code (one item), or RR_SENTINEL (empty scene)
     const float4* item_boxes; // the same padded world boxes per item: [2 i] = lo, [2 i + 1] = hi (the packet form of the top level, trace_closest_packet)
@@ -154,6 +155,10 @@ struct DRayQueue {
 //   s0 = (origin.xyz, limit)      limit = distance to the light, or +FLT_MAX for directional lights
 //   s1 = (dir.xyz, bits(receiver item | depth << 27))   the receiver's material alpha is looked up for occluded rays only
 //   s2 = (contribution rgb, bits(accumulator slot))
+// scenes whose top level has a packet form (rr_kernels.hip: beam_candidates)
+#define RR_BEAM_MAX_ITEMS 512u // 8 passes of 64 boxes: about what three steps of the per-ray walk cost
+#define RR_BEAM_MIN_ITEMS 17u  // up to 16 items the tree is two levels: the per-ray walk is cheaper than the packet's set-up
+
 struct DShadowQueue {
     float4* s0;
     float4* s1;

@@ -561,10 +561,6 @@ RR_DEV void trace_closest_nonfinite(const DSceneView& sc, f3 o, f3 d, uint32_t d
 // All 64 lanes must be active.  Returns false (nothing touched) when the packet is not coherent, the scene has more
 // items than a few passes cover, or more than 64 items survive: the caller walks the tree per ray instead.
 // ---------------------------------------------------------------------------
-#ifndef RR_BEAM_MAX_ITEMS
-#define RR_BEAM_MAX_ITEMS 512u // 8 passes of 64 boxes: about what three steps of the per-ray walk cost
-#define RR_BEAM_MIN_ITEMS 17u  // up to 16 items the tree is two levels: the per-ray walk is cheaper than the packet's set-up
-#endif
 RR_DEV float wave_min_f32(float v) {
     v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));  // quad_perm [1,0,3,2]
     v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));  // quad_perm [2,3,0,1]
@@ -749,6 +745,21 @@ RR_DEV void trace_shadow_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, f
     // The occluder found has a hit within the light distance.  Only if its sort key lies beyond the light (its box
     // contains the ray origin, so the key is the box EXIT distance) can an item that starts beyond the light precede it.
     if (sel->found && sel->within && sel->key > limit && trace_shadow_blockers(sc, o, d, depth, limit, *sel, s_stack)) sel->within = false;
+}
+
+// The packet form of trace_shadow_ray's first pass (see trace_closest_packet): candidates in box-distance order, until the
+// next box starts beyond every lane's bound (the light, or the key of the occluder selected so far).
+RR_DEV bool trace_shadow_packet(const DSceneView& sc, f3 o, f3 d, uint32_t depth, float limit, int* s_stack, ShadowSel* sel) {
+    uint32_t sk; int item;
+    if (!beam_candidates(sc, o, d, wave_max_f32(limit == limit ? limit : 0.0f), s_stack, &sk, &item)) return false;
+    sel->found = false; sel->within = false; sel->key = 0.0f; sel->item = -1; sel->t = 0.0f; sel->face = 0u;
+    float key; int idx;
+    while (beam_next(sk, item, &key, &idx)) {
+        if (__ballot(key <= RR_SHADOW_BOUND) == 0ull) break; // (a NaN light distance compares false: that lane wants nothing, as in the per-ray walk)
+        shadow_item(sc, idx, o, d, depth, limit, s_stack, 0, sel);
+    }
+    if (sel->found && sel->within && sel->key > limit && trace_shadow_blockers(sc, o, d, depth, limit, *sel, s_stack)) sel->within = false;
+    return true;
 }
 
 // ---------------------------------------------------------------------------
@@ -1165,7 +1176,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
                                                     DRayQueue qin, const uint32_t* __restrict__ qin_count,
                                                     uint32_t chunk_begin, uint32_t chunk_end,
                                                     DRayQueue qout, uint32_t* qout_count,
-                                                    DShadowQueue sq, uint32_t* sq_counts, uint32_t sq_segcap,
+                                                    DShadowQueue sq, uint32_t* sq_counts, uint32_t sq_segcap, unsigned long long* __restrict__ sq_valid, uint32_t sq_cap,
                                                     DAccum acc, unsigned long long* counters) {
     // The scene view and the frame constants (90 dwords) are read from a small device record where they are needed
     // instead of arriving as kernel arguments: as arguments they were all live in SGPRs across the whole loop and the
@@ -1193,10 +1204,18 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
         if (i < n) hit = qin.hit[i];
         const int item_idx = (int)hit.y;
         const bool active = i < n && item_idx >= 0; // miss: colour 0, depth 0, normal 0, id 0 (:728-732); buffers are pre-zeroed
-        // Shadow rays are appended densely (ballot + prefix, one atomic per wave and light) to one of
-        // RR_SQ_SHARDS sub-queues chosen by the input packet group (256 consecutive rays): a single append counter is a hot word
-        // (~90 returning atomics per microsecond) that capped this kernel at one 64-ray packet per ~11 ns.
-        // Shard capacity is static: a shard receives at most its share of the chunk's packets.
+        // LEVEL 1: shadow rays have FIXED slots.  The ray of hit i towards the k-th enabled light sits at k * sq_cap +
+        // (i - chunk_begin), and one 64-bit word per (light, packet) says which lanes hold one (sq_valid).  A packet of the
+        // shadow kernel is then the shadow rays of one packet of hits -- 64 samples of one pixel towards one light, all or
+        // none of them as a rule -- which is what its packet form of the top level needs, and nothing is allocated.
+        // DEEPER LEVELS: appended densely (ballot + prefix, one atomic per wave and light) to one of RR_SQ_SHARDS sub-queues
+        // chosen by the input packet group (256 consecutive rays; a single append counter is a hot word, ~90 returning
+        // atomics per microsecond; shard capacity is static: a shard receives at most its share of the chunk's packets).
+        // There only some lanes of a packet spawn a shadow ray, and fixed slots would trace packets a fifth full
+        // (monkey: shadow 2.1 -> 3.5 ms); so do the level-1 packets of scenes too small for the packet form (+3 .. 15 %).
+        const bool sq_fixed = PRIMARY && sq_cap != 0u; // (the host's choice: level 1 of a scene whose top level has a packet form)
+        const uint32_t sq_slot = i - chunk_begin;
+        uint32_t sq_wrote = 0u; // bit k: this lane wrote a ray for the k-th enabled light
         const uint32_t shard = ((base - chunk_begin) / RR_BLOCK) % RR_SQ_SHARDS; // the 4 packets of a workgroup iteration stay together
         uint32_t* const sq_count = sq_counts + shard * RR_SQ_STRIDE;
         const uint32_t sq_base = shard * sq_segcap;
@@ -1378,9 +1397,11 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
 
         // ---- lights (:814-920)
         const f3 view_dir = normalize3(-rd);
+        uint32_t lk = 0xffffffffu; // ordinal among the enabled lights
         for (uint32_t li = 0; li < sc.n_lights; li++) {
             const DLight& L = sc.lights[li];
             if (L.type & 0x80u) continue; // disabled
+            lk++;
             const f3 lpos = mk3(L.pos[0], L.pos[1], L.pos[2]), ldir = mk3(L.dir[0], L.dir[1], L.dir[2]);
             f3 to_light;
             if (L.type == 0u) to_light = normalize3(-ldir);
@@ -1416,8 +1437,9 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
                 nf |= nonfinite_flags(cr, cg, cb);
                 sum_r += to_fix(cr, RR_FIX_SCALE, RR_FIX_CLAMP); sum_g += to_fix(cg, RR_FIX_SCALE, RR_FIX_CLAMP); sum_b += to_fix(cb, RR_FIX_SCALE, RR_FIX_CLAMP);
             }
-            const uint32_t si = sq_base + wave_alloc(sq_count, want_shadow, lane);
+            const uint32_t si = sq_fixed ? lk * sq_cap + sq_slot : sq_base + wave_alloc(sq_count, want_shadow, lane);
             if (want_shadow) {
+                sq_wrote |= 1u << lk;
                 f3 so = hit_point + (surface_normal * 0.001f);
                 f3 sd = to_light;
                 if (mc) sd = jitter(sd, m.shadow_softness, rk, 1u + li);
@@ -1447,6 +1469,13 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
             n_secondary++;
         }
         } // active
+        if (sq_fixed) { // which lanes of this packet hold a shadow ray, per enabled light (zero words too: the shadow kernel reads them all)
+            const uint32_t pk = (base - chunk_begin) / RR_WAVE, n_pk = sq_cap / RR_WAVE;
+            for (uint32_t k = 0; k < sc.n_enabled_lights; k++) {
+                const unsigned long long mk = __ballot((sq_wrote >> k) & 1u);
+                if (lane == 0) sq_valid[k * n_pk + pk] = mk;
+            }
+        }
         if (nf) atomicOr(&acc.flags[pix_of_nf], nf); // rare: a non-finite term
         accum_merged(acc, sum_pix, sum_r, sum_g, sum_b);
         if ((acc.normal || acc.depth) && __ballot(aux_pix != 0xffffffffu) != 0ull) accum_aux_merged(acc, aux_pix, aux_nx, aux_ny, aux_nz, aux_d);
@@ -1491,24 +1520,31 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
 // ---------------------------------------------------------------------------
 // kernel 4: shadow rays of one shade chunk (reference src/raytracing.rs:872-914)
 // ---------------------------------------------------------------------------
+// FIXED (level 1): packet p = the shadow rays of hit packet (p % packets per light) towards enabled light (p / packets per
+// light), slots p * 64 .. p * 64 + 63, lanes by sq_valid[p]; n_packets given.  Otherwise the dense sharded queue of the
+// deeper levels (k_shade), n_packets from the shard counts.
+template <bool FIXED>
 __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DSceneView sc, DShadowQueue sq, const uint32_t* __restrict__ sq_counts, uint32_t sq_segcap,
+                                                           const unsigned long long* __restrict__ sq_valid, uint32_t n_fixed_packets,
                                                            uint32_t* head, DAccum acc) {
     __shared__ int s_stack[RR_STACK_DEPTH * RR_BLOCK];
     __shared__ uint32_t s_prefix[RR_SQ_SHARDS + 1];
     RR_UTIL_KIND(2u)
-    // dense index space over the shards: prefix sums of their counts
-    if (threadIdx.x < RR_WAVE) {
-        uint32_t c = threadIdx.x < RR_SQ_SHARDS ? sq_counts[threadIdx.x * RR_SQ_STRIDE] : 0u;
-        uint32_t incl = c;
-        for (int off = 1; off < RR_SQ_SHARDS; off <<= 1) { uint32_t v = __shfl_up(incl, off); if ((int)threadIdx.x >= off) incl += v; }
-        if (threadIdx.x < RR_SQ_SHARDS) s_prefix[threadIdx.x + 1] = incl;
-        if (threadIdx.x == 0) s_prefix[0] = 0u;
+    uint32_t n = 0;
+    if (!FIXED) { // dense index space over the shards: prefix sums of their counts
+        if (threadIdx.x < RR_WAVE) {
+            uint32_t c = threadIdx.x < RR_SQ_SHARDS ? sq_counts[threadIdx.x * RR_SQ_STRIDE] : 0u;
+            uint32_t incl = c;
+            for (int off = 1; off < RR_SQ_SHARDS; off <<= 1) { uint32_t v = __shfl_up(incl, off); if ((int)threadIdx.x >= off) incl += v; }
+            if (threadIdx.x < RR_SQ_SHARDS) s_prefix[threadIdx.x + 1] = incl;
+            if (threadIdx.x == 0) s_prefix[0] = 0u;
+        }
+        __syncthreads();
+        n = s_prefix[RR_SQ_SHARDS];
     }
-    __syncthreads();
-    const uint32_t n = s_prefix[RR_SQ_SHARDS];
+    const uint32_t n_packets = FIXED ? n_fixed_packets : (n + RR_WAVE - 1) / RR_WAVE;
     const uint32_t lane = threadIdx.x & (RR_WAVE - 1);
     const bool gw = sc.general_w != 0u;
-    const uint32_t n_packets = (n + RR_WAVE - 1) / RR_WAVE;
     // same packet stream as k_trace_closest: most packets dealt round-robin without an atomic (blocks of one XCD
     // take one contiguous run per round), the tail pulled one packet at a time to absorb the expensive ones
     const uint32_t n_waves = gridDim.x * (RR_BLOCK / RR_WAVE);
@@ -1535,20 +1571,30 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DScen
             p = dyn_next++; dyn_left--;
         }
         if (p >= n_packets) break;
+        unsigned long long valid;
+        if (FIXED) valid = sq_valid[p]; // (the same word in every lane)
+        else { const uint32_t left = n - p * RR_WAVE; valid = left >= RR_WAVE ? ~0ull : (1ull << left) - 1ull; }
+        if (valid == 0ull) continue;
         {
-        const uint32_t j = p * RR_WAVE + lane;
         long long sum_r = 0, sum_g = 0, sum_b = 0;
         uint32_t sum_pix = 0xffffffffu;
-        if (j < n) {
-            uint32_t lo = 0, hi = RR_SQ_SHARDS; // largest shard with prefix <= j
-            while (hi - lo > 1u) { uint32_t mid = (lo + hi) >> 1; if (s_prefix[mid] <= j) lo = mid; else hi = mid; }
-            const uint32_t i = lo * sq_segcap + (j - s_prefix[lo]);
+        const bool live = ((valid >> lane) & 1ull) != 0ull;
+        {
+            // lanes without a ray repeat the packet's first one (the packet form runs with all lanes) and add nothing
+            const uint32_t j = p * RR_WAVE + (live ? lane : (uint32_t)__ffsll((long long)valid) - 1u);
+            uint32_t i = j;
+            if (!FIXED) {
+                uint32_t lo = 0, hi = RR_SQ_SHARDS; // largest shard with prefix <= j
+                while (hi - lo > 1u) { uint32_t mid = (lo + hi) >> 1; if (s_prefix[mid] <= j) lo = mid; else hi = mid; }
+                i = lo * sq_segcap + (j - s_prefix[lo]);
+            }
             const float4 s0 = sq.s0[i];
             const float4 s1 = sq.s1[i], s2 = sq.s2[i];
             const uint32_t rcv_item = __float_as_uint(s1.w) & 0x07ffffffu, rcv_depth = __float_as_uint(s1.w) >> 27;
             const f3 o = mk3(s0.x, s0.y, s0.z), d = mk3(s1.x, s1.y, s1.z);
             ShadowSel sel;
-            trace_shadow_ray(sc, o, d, rcv_depth, s0.w, s_stack, &sel);
+            if (!FIXED || !trace_shadow_packet(sc, o, d, rcv_depth, s0.w, s_stack, &sel)) { if (live) trace_shadow_ray(sc, o, d, rcv_depth, s0.w, s_stack, &sel); }
+            if (live) {
             const bool occluded = sel.found && sel.within;
             float factor = 1.0f;
             if (occluded) {
@@ -1572,6 +1618,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DScen
             const uint32_t nf = nonfinite_flags(vr_, vg_, vb_);
             sum_r = to_fix(vr_, RR_FIX_SCALE, RR_FIX_CLAMP); sum_g = to_fix(vg_, RR_FIX_SCALE, RR_FIX_CLAMP); sum_b = to_fix(vb_, RR_FIX_SCALE, RR_FIX_CLAMP);
             if (nf) atomicOr(&acc.flags[sum_pix], nf);
+            }
         }
         accum_merged(acc, sum_pix, sum_r, sum_g, sum_b);
         }
