@@ -153,6 +153,11 @@ RR_DEV bool ray_ball(float radius, const LRay& ray, bool solid, float* toi_out, 
 // BVH4 traversal (DNode4, rr_device.h).  Per-lane stack in LDS, lane-interleaved (conflict free), terminated by a
 // sentinel entry instead of a depth test.
 // ---------------------------------------------------------------------------
+// A scene pointer is a GLOBAL pointer.  The trace kernels get the scene view as kernel arguments and the compiler knows;
+// k_shade reads it from a device record (DShadeConst), where a pointer loaded from memory is generic and every access
+// through it becomes a flat_load (aperture check, counted against both vmcnt and lgkmcnt).  The integer round trip gives
+// the optimiser the address space back.
+template <class T> RR_DEV const T* rr_global(const T* p) { return (const T*)(const __attribute__((address_space(1))) T*)(uintptr_t)p; }
 #define STK(sp) s_stack[(sp) * RR_BLOCK + threadIdx.x]
 #define RR_SENTINEL ((int)0x80000000) // bottom of every stack; root of an empty tree
 
@@ -474,7 +479,7 @@ struct Closest { float t; int item; uint32_t face; float key; bool found; };
 RR_DEV void closest_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t depth,
                          int* s_stack, int sp_base, Closest* best) {
     RR_UTIL(1)
-    const DItem& it = sc.items[idx];
+    const DItem& it = rr_global(sc.items)[idx];
     uint32_t flags = it.flags;
     if (!item_passes(flags, false, depth)) return;
     LRay lr = inverse_ray(it, o, d, sc.general_w != 0u);
@@ -535,7 +540,7 @@ RR_DEV void trace_closest_nonfinite(const DSceneView& sc, f3 o, f3 d, uint32_t d
     best->found = false; best->t = RR_FLT_MAX; best->item = -1; best->face = 0u; best->key = 0.0f;
     Closest first = *best; // the first candidate in the reference's order that is hit at all
     for (int idx = 0; idx < (int)sc.n_items; idx++) {
-        const DItem& it = sc.items[idx];
+        const DItem& it = rr_global(sc.items)[idx];
         const uint32_t flags = it.flags;
         if (!(flags & RR_IF_SPHERE) || !item_passes(flags, false, depth)) continue;
         LRay lr = inverse_ray(it, o, d, sc.general_w != 0u);
@@ -665,7 +670,7 @@ struct ShadowSel { float key; int item; bool found; bool within; float t; uint32
 RR_DEV void shadow_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t depth, float limit,
                         int* s_stack, int sp_base, ShadowSel* sel) {
     RR_UTIL(1)
-    const DItem& it = sc.items[idx];
+    const DItem& it = rr_global(sc.items)[idx];
     uint32_t flags = it.flags;
     if (!item_passes(flags, true, depth)) return;
     LRay lr = inverse_ray(it, o, d, sc.general_w != 0u);
@@ -698,7 +703,7 @@ RR_DEV void shadow_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t dept
 // first one that is hit decides (src/raytracing.rs:466-487); its hit lies beyond the light, so the receiver is lit.
 RR_DEV bool shadow_blocker_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t depth, float limit, const ShadowSel& sel,
                                 int* s_stack, int sp_base) {
-    const DItem& it = sc.items[idx];
+    const DItem& it = rr_global(sc.items)[idx];
     const uint32_t flags = it.flags;
     if (!item_passes(flags, true, depth)) return false;
     LRay lr = inverse_ray(it, o, d, sc.general_w != 0u);
@@ -767,7 +772,7 @@ RR_DEV bool trace_shadow_packet(const DSceneView& sc, f3 o, f3 d, uint32_t depth
 // ---------------------------------------------------------------------------
 // `lut`: the u8 -> f32 table (c_u8_to_f32, or a workgroup's copy of it in LDS: four dependent reads per texel)
 RR_DEV float4 texel(const DSceneView& sc, const DTexture& t, uint32_t x, uint32_t y, const float* lut = c_u8_to_f32) {
-    uint32_t p = sc.texels[t.offset + (uint64_t)y * t.width + x];
+    uint32_t p = rr_global(sc.texels)[t.offset + (uint64_t)y * t.width + x];
     return make_float4(lut[p & 255u], lut[(p >> 8) & 255u], lut[(p >> 16) & 255u], lut[p >> 24]);
 }
 RR_DEV uint32_t tex_wrap(float val, uint32_t bound) {
@@ -819,7 +824,7 @@ RR_DEV MatR load_material(const DMaterial* p, const float* lut) {
 }
 RR_DEV bool tex_color(const DSceneView& sc, const MatR& m, bool has_uv, f2 uv, int slot, float4* out) {
     if (!(m.flags & (RR_MF_TEX_SLOT0 << slot)) || !has_uv) return false; // slot bit = index >= 0 and width > 0
-    const DTexture t = sc.textures[m.p->tex[slot]];
+    const DTexture t = rr_global(sc.textures)[m.p->tex[slot]];
     if (m.flags & RR_MF_NEAREST) *out = texel(sc, t, tex_wrap(uv.x, t.width), tex_wrap(uv.y, t.height), m.lut);
     else *out = tex_bilinear(sc, t, uv.x, uv.y, m.lut);
     return true;
@@ -828,7 +833,7 @@ RR_DEV bool tex_color(const DSceneView& sc, const MatR& m, bool has_uv, f2 uv, i
 RR_DEV bool tex_color(const DSceneView& sc, const DMaterial& m, bool has_uv, f2 uv, int slot, float4* out) {
     int ti = m.tex[slot];
     if (ti < 0 || !has_uv) return false;
-    const DTexture t = sc.textures[ti];
+    const DTexture t = rr_global(sc.textures)[ti];
     if (t.width == 0u) return false;
     if (m.flags & RR_MF_NEAREST) *out = texel(sc, t, tex_wrap(uv.x, t.width), tex_wrap(uv.y, t.height));
     else *out = tex_bilinear(sc, t, uv.x, uv.y);
@@ -855,10 +860,10 @@ RR_DEV f2 sphere_uv(const DItem& it, f3 hit, bool general_w) {
 }
 RR_DEV f2 mesh_uv(const DSceneView& sc, const DItem& it, uint32_t slot, f3 hit, bool general_w) {
     f2 r; r.x = 0.0f; r.y = 0.0f;
-    const DTriAttr at = sc.attrs[it.tri_base + slot];
+    const DTriAttr at = rr_global(sc.attrs)[it.tri_base + slot];
     if (!(__float_as_uint(at.s3.w) & 1u)) return r;
     f3 p = to_local_point(it, hit, general_w);
-    const DTri tr = sc.tris[it.tri_base + slot];
+    const DTri tr = rr_global(sc.tris)[it.tri_base + slot];
     float a1, a2, a3;
     area_weights(mk3(tr.v0.x, tr.v0.y, tr.v0.z), mk3(tr.v1.x, tr.v1.y, tr.v1.z), mk3(tr.v2.x, tr.v2.y, tr.v2.z), p, &a1, &a2, &a3);
     float ux = (at.s0.w * a1 + at.s2.w * a2) + at.s3.y * a3;
@@ -1242,9 +1247,9 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
         const uint32_t sample = meta & 0xffffu, depth = (meta >> 16) & 0xffu;
         const bool idc = ((meta >> 24) & 1u) != 0u;
         const float thr = r0.w;
-        const DItem& it = sc.items[item_idx];
+        const DItem& it = rr_global(sc.items)[item_idx];
         const uint32_t it_flags = it.flags, it_tri_base = it.tri_base, it_id = it.id; // register copies (see MatR)
-        const MatR m = load_material(&sc.materials[it.material], s_lut);
+        const MatR m = load_material(&rr_global(sc.materials)[it.material], s_lut);
         const f3 ro = mk3(r0.x, r0.y, r0.z), rd = mk3(r1.x, r1.y, r1.z);
         const float hit_dist = __uint_as_float(hit.x);
         const f3 hit_point = ro + (rd * hit_dist);
@@ -1262,12 +1267,12 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
             f3 nl = normalize3(lr.o + lr.d * t2);
             normal = to_world_normal(it, inside ? -nl : nl);
         } else {
-            const DTri tr = sc.tris[it_tri_base + slot];
+            const DTri tr = rr_global(sc.tris)[it_tri_base + slot];
             const f3 a = mk3(tr.v0.x, tr.v0.y, tr.v0.z), b = mk3(tr.v1.x, tr.v1.y, tr.v1.z), c = mk3(tr.v2.x, tr.v2.y, tr.v2.z);
             // the area weights of the hit point serve the interpolated normal AND the uv (Mesh::get_normal and
             // Mesh::get_uv compute the same three numbers from the same inputs, src/shape/mesh.rs:105-161, :204-259)
             if ((it_flags & RR_IF_SMOOTH) || (m.flags & RR_MF_ANY_TEX)) {
-                at = sc.attrs[it_tri_base + slot];
+                at = rr_global(sc.attrs)[it_tri_base + slot];
                 const f3 p = to_local_point(it, hit_point, gw);
                 area_weights(a, b, c, p, &a1, &a2, &a3);
                 have_weights = true;
@@ -1399,7 +1404,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
         const f3 view_dir = normalize3(-rd);
         uint32_t lk = 0xffffffffu; // ordinal among the enabled lights
         for (uint32_t li = 0; li < sc.n_lights; li++) {
-            const DLight& L = sc.lights[li];
+            const DLight& L = rr_global(sc.lights)[li];
             if (L.type & 0x80u) continue; // disabled
             lk++;
             const f3 lpos = mk3(L.pos[0], L.pos[1], L.pos[2]), ldir = mk3(L.dir[0], L.dir[1], L.dir[2]);
@@ -1598,18 +1603,18 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DScen
             const bool occluded = sel.found && sel.within;
             float factor = 1.0f;
             if (occluded) {
-                float shadow_source_alpha = sc.materials[sc.items[rcv_item].material].alpha; // the RECEIVER's material.alpha (:898)
-                const DItem& occ = sc.items[sel.item];
+                float shadow_source_alpha = rr_global(sc.materials)[rr_global(sc.items)[rcv_item].material].alpha; // the RECEIVER's material.alpha (:898)
+                const DItem& occ = rr_global(sc.items)[sel.item];
                 if (occ.flags & RR_IF_OCCLUDER_ALPHA_TEX) {
                     // the reference evaluates the RECEIVER's get_uv with the occluder's face id (:905)
-                    const DItem& rcv = sc.items[rcv_item];
+                    const DItem& rcv = rr_global(sc.items)[rcv_item];
                     const f3 shp = o + (d * sel.t);
                     f2 uv;
                     if (rcv.flags & RR_IF_SPHERE) uv = sphere_uv(rcv, shp, gw);
-                    else if (rcv.n_tris != 0u) uv = mesh_uv(sc, rcv, sc.face_slot[rcv.tri_base + sel.face % rcv.n_tris], shp, gw);
+                    else if (rcv.n_tris != 0u) uv = mesh_uv(sc, rcv, rr_global(sc.face_slot)[rcv.tri_base + sel.face % rcv.n_tris], shp, gw);
                     else { uv.x = 0.0f; uv.y = 0.0f; }
                     float4 tc;
-                    if (tex_color(sc, sc.materials[occ.material], true, uv, 4, &tc)) shadow_source_alpha *= tc.x;
+                    if (tex_color(sc, rr_global(sc.materials)[occ.material], true, uv, 4, &tc)) shadow_source_alpha *= tc.x;
                 }
                 factor = 1.0f - shadow_source_alpha;
             }
