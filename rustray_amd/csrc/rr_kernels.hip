@@ -277,14 +277,36 @@ RR_DEV float4 node_row_uniform(const DNode4* nodes, uint32_t byte_off) {
         RR_CHILD(k1, h1, nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y)                                       \
         RR_CHILD(k2, h2, nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x)                                       \
         RR_CHILD(k3, h3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y)
+// Two thirds of the node steps of the contract frame have at most ONE child hit in every lane (9.6 % have more than two):
+// then nothing is ordered and nothing is pushed.  The test is scalar (the hit flags are lane masks).  Closest-hit walks
+// only (-1 % sponza_syn, -3 % lotus_syn): the shadow kernel, at its register limit, loses 3 % to it.
+#define RR_NODE4_SINGLE_HIT                                                                                    \
+        const bool multi_ = (h0 && (h1 || h2 || h3)) || (h1 && (h2 || h3)) || (h2 && h3);                      \
+        if (__ballot(multi_) == 0ull) {                                                                        \
+            const int c_ = __float_as_int(h0 ? cc.x : (h1 ? cc.y : (h2 ? cc.z : cc.w)));                       \
+            if (h0 || h1 || h2 || h3) cur = c_;                                                                \
+            else { sp--; cur = STK(sp); }                                                                      \
+        } else
 #define RR_NODE4_DESCEND_SORTED                                                                                \
+        RR_NODE4_SINGLE_HIT {                                                                                  \
         int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w); \
         RR_CSWAP(k0, c0, k1, c1) RR_CSWAP(k2, c2, k3, c3) RR_CSWAP(k0, c0, k2, c2) RR_CSWAP(k1, c1, k3, c3) RR_CSWAP(k1, c1, k2, c2) \
         STK(sp) = c3; sp += (k3 < inf_) ? 1 : 0;                                                               \
         STK(sp) = c2; sp += (k2 < inf_) ? 1 : 0;                                                               \
         STK(sp) = c1; sp += (k1 < inf_) ? 1 : 0;                                                               \
         if (k0 < inf_) cur = c0;                                                                               \
-        else { sp--; cur = STK(sp); }
+        else { sp--; cur = STK(sp); }                                                                          \
+        }
+#define RR_NODE4_DESCEND_SORTED_PLAIN                                                                          \
+        {                                                                                                      \
+        int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w); \
+        RR_CSWAP(k0, c0, k1, c1) RR_CSWAP(k2, c2, k3, c3) RR_CSWAP(k0, c0, k2, c2) RR_CSWAP(k1, c1, k3, c3) RR_CSWAP(k1, c1, k2, c2) \
+        STK(sp) = c3; sp += (k3 < inf_) ? 1 : 0;                                                               \
+        STK(sp) = c2; sp += (k2 < inf_) ? 1 : 0;                                                               \
+        STK(sp) = c1; sp += (k1 < inf_) ? 1 : 0;                                                               \
+        if (k0 < inf_) cur = c0;                                                                               \
+        else { sp--; cur = STK(sp); }                                                                          \
+        }
 #define RR_NODE4_DESCEND_ANY                                                                                   \
         (void)k0; (void)k1; (void)k2; (void)k3;                                                                \
         STK(sp) = __float_as_int(cc.w); sp += h3 ? 1 : 0;                                                      \
@@ -311,6 +333,7 @@ RR_DEV float4 node_row_uniform(const DNode4* nodes, uint32_t byte_off) {
     }
 #endif
 #define RR_NODE4_STEP(nodes4, s4, bound) RR_NODE4_FORM(nodes4, s4, bound, RR_NODE4_DESCEND_SORTED)
+#define RR_NODE4_STEP_PLAIN(nodes4, s4, bound) RR_NODE4_FORM(nodes4, s4, bound, RR_NODE4_DESCEND_SORTED_PLAIN)
 // The same step for walks that only ask whether anything is hit (shadow queries inside one mesh): the order in which
 // the children are visited does not matter, so the hit children are pushed in slot order and the sort is skipped.
 #define RR_NODE4_STEP_ANY(nodes4, s4, bound) RR_NODE4_FORM(nodes4, s4, bound, RR_NODE4_DESCEND_ANY)
@@ -725,7 +748,7 @@ RR_DEV bool trace_shadow_blockers(const DSceneView& sc, f3 o, f3 d, uint32_t dep
     STK(0) = RR_SENTINEL;
     int cur = sc.tlas_root4;
     for (;;) {
-        while (cur >= 0) { RR_NODE4_STEP(sc.tnodes4, ws, bound) }
+        while (cur >= 0) { RR_NODE4_STEP_PLAIN(sc.tnodes4, ws, bound) }
         if (cur == RR_SENTINEL) break;
         if (shadow_blocker_item(sc, (int)RR_LEAF_FIRST((uint32_t)~cur), o, d, depth, limit, sel, s_stack, sp)) return true;
         sp--; cur = STK(sp);
@@ -742,7 +765,7 @@ RR_DEV void trace_shadow_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, f
     STK(0) = RR_SENTINEL;
     int cur = sc.tlas_root4;
     for (;;) {
-        while (cur >= 0) { RR_NODE4_STEP(sc.tnodes4, ws, RR_SHADOW_BOUND) }
+        while (cur >= 0) { RR_NODE4_STEP_PLAIN(sc.tnodes4, ws, RR_SHADOW_BOUND) }
         if (cur == RR_SENTINEL) break;
         shadow_item(sc, (int)RR_LEAF_FIRST((uint32_t)~cur), o, d, depth, limit, s_stack, sp, sel);
         sp--; cur = STK(sp);

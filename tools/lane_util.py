@@ -33,3 +33,5 @@ with capi.DeviceScene(fs, 0) as ds:
                 uni, uni2 = buf[30 + 10 * k + 2 * slot], buf[30 + 10 * k + 2 * slot + 1]
                 print(f"  {kn:28s} {nm:30s} wave-steps {n:12d}  lane-steps per ray {lanes / max(rays[k], 1):7.2f}  avg active lanes {lanes / n:5.1f} / 64"
                       + (f"  same address in all active lanes {uni / n:5.1%}, and same direction signs {uni2 / n:5.1%}" if slot in (0, 2, 3) else ""))
+    if buf[62]:
+        print(f"  node steps in which no lane has more than one child hit {buf[60] / buf[62]:5.1%}, more than two {1 - buf[61] / buf[62]:5.1%} (all ray kinds)")
