@@ -175,10 +175,14 @@ __shared__ uint32_t s_util_kind; // 0: closest-hit level 1, 1: closest-hit deepe
         const bool u1_ = __ballot(a_ == ua_) == m_; const bool u2_ = u1_ && __ballot(k_ == uk_) == m_;                                       \
         if ((int)(threadIdx.x & 63u) == l_) { if (u1_) atomicAdd(&g_util[30 + 10 * s_util_kind + 2 * (slot)], 1ull);                         \
                                               if (u2_) atomicAdd(&g_util[30 + 10 * s_util_kind + 2 * (slot) + 1], 1ull); } }
+// node steps in which no lane has more than one (g_util[60]) / two (61) children hit, of all node steps (62)
+#define RR_UTIL_ONE { const int nh_ = (int)h0 + (int)h1 + (int)h2 + (int)h3; const unsigned long long m_ = __ballot(1); const bool one_ = __ballot(nh_ > 1) == 0ull; const bool two_ = __ballot(nh_ > 2) == 0ull; \
+        if ((int)(threadIdx.x & 63u) == __ffsll((long long)m_) - 1) { if (one_) atomicAdd(&g_util[60], 1ull); if (two_) atomicAdd(&g_util[61], 1ull); atomicAdd(&g_util[62], 1ull); } }
 #else
 #define RR_UTIL(slot)
 #define RR_UTIL_KIND(k)
 #define RR_UTIL_UNI(slot, addr, key2)
+#define RR_UTIL_ONE
 #endif
 
 // The traversal's own box test is NOT part of the parity contract (only the exact primitive tests decide
@@ -276,7 +280,7 @@ RR_DEV float4 node_row_uniform(const DNode4* nodes, uint32_t byte_off) {
         RR_CHILD(k0, h0, nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x)                                       \
         RR_CHILD(k1, h1, nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y)                                       \
         RR_CHILD(k2, h2, nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x)                                       \
-        RR_CHILD(k3, h3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y)
+        RR_CHILD(k3, h3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y) RR_UTIL_ONE
 // Two thirds of the node steps of the contract frame have at most ONE child hit in every lane (9.6 % have more than two):
 // then nothing is ordered and nothing is pushed.  The test is scalar (the hit flags are lane masks).  Closest-hit walks
 // only (-1 % sponza_syn, -3 % lotus_syn): the shadow kernel, at its register limit, loses 3 % to it.
