@@ -16,7 +16,7 @@ import sys
 tag, name = sys.argv[1], sys.argv[2]
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
-KERNELS = ("k_trace_closest", "k_trace_closest<true>", "k_trace_closest<false>", "k_trace_shadow", "k_shade", "k_shade<true>", "k_shade<false>", "k_resolve")
+KERNELS = ("k_trace_closest", "k_trace_closest<true>", "k_trace_closest<false>", "k_trace_shadow", "k_trace_shadow<true>", "k_trace_shadow<false>", "k_shade", "k_shade<true>", "k_shade<false>", "k_resolve")
 
 
 def kname(raw):
@@ -27,7 +27,7 @@ def kname(raw):
 
 def with_totals(d, combine):
     """adds 'k_x' = combine over 'k_x<true>' and 'k_x<false>' (level 1 and the deeper levels of one kernel)"""
-    for base in ("k_trace_closest", "k_shade"):
+    for base in ("k_trace_closest", "k_trace_shadow", "k_shade"):
         parts = [d[k] for k in (base + "<true>", base + "<false>") if k in d]
         if parts and base not in d:
             d[base] = combine(parts)
