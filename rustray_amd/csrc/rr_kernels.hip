@@ -365,6 +365,50 @@ struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool foun
 #define RR_PEND_DEN 3
 #endif
 
+#define RR_TRI_CLOSEST(tr, slot_)                                                                               \
+            {                                                                                                  \
+                float t; uint32_t side;                                                                        \
+                if (ray_triangle(mk3(tr.t0.x, tr.t0.y, tr.t0.z), mk3(tr.t1.x, tr.t1.y, tr.t1.z),               \
+                                 mk3(tr.t1.w, tr.t2.x, tr.t2.y), ray, &t, &side)) {                            \
+                    const uint32_t face = __float_as_uint(tr.t0.w);                                            \
+                    if (!best.found || t < best.t || (t == best.t && face < best.face)) {                      \
+                        best.found = true; best.t = t; best.slot = (slot_); best.face = face; best.side = side; \
+                    }                                                                                          \
+                }                                                                                              \
+            }
+// A leaf that is the same in every lane of a walk that shares its tree (three quarters of the triangle tests of level 1)
+// is fetched through the scalar cache, TWO triangles per wait: the tests of a leaf are a chain of load -> test -> load.
+#define RR_TRI_FETCH(t_, o_) t_.t0 = node_row_uniform((const DNode4*)sc.trix, o_); t_.t1 = node_row_uniform((const DNode4*)sc.trix, (o_) + 16u); t_.t2 = node_row_uniform((const DNode4*)sc.trix, (o_) + 32u);
+#ifndef RR_NO_SCALAR_LEAVES
+#define RR_LEAF_CLOSEST(leaf)                                                                                  \
+    {                                                                                                          \
+        const int uleaf_ = __builtin_amdgcn_readfirstlane(leaf);                                               \
+        const uint32_t utri_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)tri_base_);                       \
+        /* (the triangle base is compared too: meshes small enough to be ONE leaf add no nodes and share a node base) */ \
+        if (SCALAR_LEAVES && sr.uni && __ballot((leaf) != uleaf_ || tri_base_ != utri_) == 0ull) {                              \
+            const uint32_t ucode = (uint32_t)~uleaf_;                                                          \
+            const uint32_t ufirst = RR_LEAF_FIRST(ucode), ucount = RR_LEAF_COUNT(ucode);                       \
+            const uint32_t ubase = utri_ + ufirst;                                                             \
+            for (uint32_t i = 0; i < ucount; i += 2u) {                                                        \
+                RR_UTIL(3)                                                                                     \
+                const bool two_ = i + 1u < ucount;                                                             \
+                const uint32_t o0 = (ubase + i) * 48u, o1 = (ubase + i + (two_ ? 1u : 0u)) * 48u;              \
+                DTriX ta, tb;                                                                                  \
+                RR_TRI_FETCH(ta, o0) RR_TRI_FETCH(tb, o1)                                                      \
+                RR_TRI_CLOSEST(ta, ufirst + i)                                                                 \
+                if (two_) RR_TRI_CLOSEST(tb, ufirst + i + 1u)                                                  \
+            }                                                                                                  \
+        } else {                                                                                               \
+            const uint32_t code = (uint32_t)~(leaf);                                                           \
+            const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);                           \
+            for (uint32_t i = 0; i < count; i++) {                                                             \
+                RR_UTIL(3) RR_UTIL_UNI(3, tri_base_ + first + i, 0)                                            \
+                const DTriX tr = tri_at(sc.trix, (tri_base_ + first + i) * 48u);                               \
+                RR_TRI_CLOSEST(tr, first + i)                                                                  \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+#else
 #define RR_LEAF_CLOSEST(leaf)                                                                                  \
     {                                                                                                          \
         const uint32_t code = (uint32_t)~(leaf);                                                               \
@@ -372,16 +416,10 @@ struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool foun
         for (uint32_t i = 0; i < count; i++) {                                                                 \
             RR_UTIL(3) RR_UTIL_UNI(3, tri_base_ + first + i, 0)                                                \
             const DTriX tr = tri_at(sc.trix, (tri_base_ + first + i) * 48u);                                   \
-            float t; uint32_t side;                                                                            \
-            if (ray_triangle(mk3(tr.t0.x, tr.t0.y, tr.t0.z), mk3(tr.t1.x, tr.t1.y, tr.t1.z),                   \
-                             mk3(tr.t1.w, tr.t2.x, tr.t2.y), ray, &t, &side)) {                                \
-                const uint32_t face = __float_as_uint(tr.t0.w);                                                \
-                if (!best.found || t < best.t || (t == best.t && face < best.face)) {                          \
-                    best.found = true; best.t = t; best.slot = first + i; best.face = face; best.side = side;  \
-                }                                                                                              \
-            }                                                                                                  \
+            RR_TRI_CLOSEST(tr, first + i)                                                                      \
         }                                                                                                      \
     }
+#endif
 #define RR_LEAF_ANY(leaf)                                                                                      \
     {                                                                                                          \
         const uint32_t code = (uint32_t)~(leaf);                                                               \
@@ -398,6 +436,8 @@ struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool foun
         }                                                                                                      \
     }
 
+// SCALAR_LEAVES: the closest-hit kernels' form (see RR_LEAF_CLOSEST); the shadow kernel, at its register limit, keeps the plain loop.
+template <bool SCALAR_LEAVES>
 RR_DEV void blas_closest(const DSceneView& sc, const DItem& it, const LRay& ray, float gbound,
                          int* s_stack, int sp_base, TriBest* out) {
     TriBest best; best.found = false; best.t = RR_FLT_MAX; best.slot = 0; best.face = 0xffffffffu; best.side = 0u;
@@ -522,7 +562,7 @@ RR_DEV void closest_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t dep
     } else {
         if (it.n_tris == 0u) return;
         TriBest tb;
-        blas_closest(sc, it, lr, best->found ? best->t : RR_FLT_MAX, s_stack, sp_base, &tb);
+        blas_closest<true>(sc, it, lr, best->found ? best->t : RR_FLT_MAX, s_stack, sp_base, &tb);
         if (!tb.found) return;
         t = tb.t;
         face = tb.slot | (tb.side << 30); // bit31 back face, bit30 negated normal
@@ -716,7 +756,7 @@ RR_DEV void shadow_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t dept
     } else if (it.n_tris != 0u) {
         if (flags & RR_IF_OCCLUDER_ALPHA_TEX) { // the occluder's alpha map needs the true nearest hit
             TriBest tb;
-            blas_closest(sc, it, lr, RR_FLT_MAX, s_stack, sp_base, &tb);
+            blas_closest<false>(sc, it, lr, RR_FLT_MAX, s_stack, sp_base, &tb);
             if (tb.found) { any = true; t = tb.t; within = t <= limit; face = tb.face + ((tb.side & 2u) ? it.n_tris : 0u); }
         } else {
             blas_any(sc, it, lr, limit, s_stack, sp_base, &any, &within);
