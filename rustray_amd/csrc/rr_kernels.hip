@@ -1021,14 +1021,45 @@ template <int N> RR_DEV bool wave_merge_runs(uint32_t pix, unsigned long long (&
     const int next_head = RR_DPP_SHL(head, 1);
     return (lane16 == 15u || next_head != 0) && pix != 0xffffffffu;
 }
+// The same over 32-bit values: when every value of the wave is below 2^25 in magnitude (a colour term up to 2, any
+// normal) a run of at most 16 of them sums to less than 2^29, and a step is one DPP add per value instead of a
+// 64-bit add with its carry and two moves.
+#define RR_SEG_STEP32(n)                                                                                       \
+    {                                                                                                          \
+        const int pf = RR_DPP_SHR(f, n);                                                                       \
+        _Pragma("unroll") for (int k_ = 0; k_ < N; k_++) { const int p_ = RR_DPP_SHR(v[k_], n); if (!f) v[k_] += p_; } \
+        if (!f) f = pf;                                                                                        \
+    }
+template <int N> RR_DEV bool wave_merge_runs32(uint32_t pix, int (&v)[N]) {
+    const uint32_t lane16 = threadIdx.x & 15u;
+    const uint32_t prev = (uint32_t)RR_DPP_SHR(pix, 1);
+    const int head = (lane16 == 0u || prev != pix) ? 1 : 0;
+    int f = head;
+    RR_SEG_STEP32(1) RR_SEG_STEP32(2) RR_SEG_STEP32(4) RR_SEG_STEP32(8)
+    const int next_head = RR_DPP_SHL(head, 1);
+    return (lane16 == 15u || next_head != 0) && pix != 0xffffffffu;
+}
+RR_DEV bool fits25(long long a, long long b, long long c) { // |a|, |b|, |c| < 2^25
+    const unsigned long long m = (unsigned long long)(a + (1ll << 25)) | (unsigned long long)(b + (1ll << 25)) | (unsigned long long)(c + (1ll << 25));
+    return (m >> 26) == 0ull;
+}
 RR_DEV void accum_merged(const DAccum& acc, uint32_t pix, long long r, long long g, long long b) {
 #ifdef RR_EXP_NO_ATOMICS
     if (r == 123456789ll) acc.rgb[pix] = 0; // timing experiment only
     return;
 #endif
+    unsigned long long* p = (unsigned long long*)acc.rgb + pix; // one plane per channel
+    if (__ballot(!fits25(r, g, b)) == 0ull) {
+        int w[3] = {(int)r, (int)g, (int)b};
+        if (wave_merge_runs32<3>(pix, w)) {
+            if (w[0]) atomicAdd(p, (unsigned long long)(long long)w[0]);
+            if (w[1]) atomicAdd(p + acc.n, (unsigned long long)(long long)w[1]);
+            if (w[2]) atomicAdd(p + 2ull * acc.n, (unsigned long long)(long long)w[2]);
+        }
+        return;
+    }
     unsigned long long v[3] = {(unsigned long long)r, (unsigned long long)g, (unsigned long long)b};
     if (wave_merge_runs<3>(pix, v)) {
-        unsigned long long* p = (unsigned long long*)acc.rgb + pix; // one plane per channel
         if (v[0]) atomicAdd(p, v[0]);
         if (v[1]) atomicAdd(p + acc.n, v[1]);
         if (v[2]) atomicAdd(p + 2ull * acc.n, v[2]);
@@ -1038,6 +1069,20 @@ RR_DEV void accum_merged(const DAccum& acc, uint32_t pix, long long r, long long
 // the samples of a pixel sit in neighbouring lanes, and 64 lanes adding to one address serialise in the L2 atomic
 // units (measured: k_shade 6.5 -> 42.8 ms on sponza_syn when the four aux adds of every primary hit went out unmerged).
 RR_DEV void accum_aux_merged(const DAccum& acc, uint32_t pix, long long nx, long long ny, long long nz, long long depth) {
+    if (__ballot(!fits25(nx, ny, nz)) == 0ull) { // the normal in 32 bits, the depth (x 2^16: up to 2^46) in 64
+        int w[3] = {(int)nx, (int)ny, (int)nz};
+        unsigned long long d[1] = {(unsigned long long)depth};
+        const bool last32 = wave_merge_runs32<3>(pix, w);
+        const bool last64 = wave_merge_runs<1>(pix, d);
+        if (last32 && acc.normal) {
+            unsigned long long* np = (unsigned long long*)acc.normal + pix;
+            if (w[0]) atomicAdd(np, (unsigned long long)(long long)w[0]);
+            if (w[1]) atomicAdd(np + acc.n, (unsigned long long)(long long)w[1]);
+            if (w[2]) atomicAdd(np + 2ull * acc.n, (unsigned long long)(long long)w[2]);
+        }
+        if (last64 && acc.depth && d[0]) atomicAdd((unsigned long long*)acc.depth + pix, d[0]);
+        return;
+    }
     unsigned long long v[4] = {(unsigned long long)nx, (unsigned long long)ny, (unsigned long long)nz, (unsigned long long)depth};
     if (wave_merge_runs<4>(pix, v)) {
         if (acc.normal) {
