@@ -946,7 +946,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     // equal batches (a frame that needs 1.2 batches would otherwise end with a small, poorly filled one)
     { const uint64_t nb = (total_primary + B - 1) / B; B = (total_primary + nb - 1) / nb; }
     if (B > npix) B = ((B + npix - 1) / npix) * npix; // whole sample slices when possible
-    // Sample grouping: a packet of 64 primary rays = 64/G neighbouring pixels x G samples of each (k_raygen), so the
+    // Sample grouping: a packet of 64 primary rays = 64/G neighbouring pixels x G samples of each (primary_ray), so the
     // rays of a wave - and the shadow rays and children they spawn - start almost identical and their walks stay
     // together.  The largest group the sample count allows is best (closest-hit -30 % on sponza_syn at G = 64 against
     // one sample of 64 pixels), given that the wave merges its accumulator adds per pixel first (accum_merged): 64

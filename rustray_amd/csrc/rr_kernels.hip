@@ -997,7 +997,7 @@ RR_DEV uint32_t nonfinite_flags(float r, float g, float b) {
     return f;
 }
 // Adds of one wave to the accumulators, merged: neighbouring lanes that add to the same pixel (the samples of one
-// pixel sit in neighbouring lanes, k_raygen; compaction keeps lane order) are summed first with a segmented scan over
+// pixel sit in neighbouring lanes, primary_ray; compaction keeps lane order) are summed first with a segmented scan over
 // the 16-lane DPP rows, and only the last lane of each run issues the atomics.  Integer adds commute, so the frame
 // is the same whatever is merged.  Must be called by all 64 lanes of the wave; lanes with nothing to add pass
 // pix = 0xffffffff.  (64 lanes adding to one address, or 16, serialise in the L2 atomic units: +10 ms on sponza_syn.)
@@ -1044,10 +1044,6 @@ RR_DEV bool fits25(long long a, long long b, long long c) { // |a|, |b|, |c| < 2
     return (m >> 26) == 0ull;
 }
 RR_DEV void accum_merged(const DAccum& acc, uint32_t pix, long long r, long long g, long long b) {
-#ifdef RR_EXP_NO_ATOMICS
-    if (r == 123456789ll) acc.rgb[pix] = 0; // timing experiment only
-    return;
-#endif
     unsigned long long* p = (unsigned long long*)acc.rgb + pix; // one plane per channel
     if (__ballot(!fits25(r, g, b)) == 0ull) {
         int w[3] = {(int)r, (int)g, (int)b};
