@@ -34,6 +34,10 @@
 #ifndef RR_DYN_FETCH
 #define RR_DYN_FETCH 4
 #endif
+#ifndef RR_SHADOW_FIXED_STATIC_NUM
+#define RR_SHADOW_FIXED_STATIC_NUM 7 // level 1 (fixed slots): sponza_syn shadow 6.3 -> 6.0 ms against one half
+#define RR_SHADOW_FIXED_STATIC_DEN 8
+#endif
 #ifndef RR_SHADOW_STATIC_NUM
 #define RR_SHADOW_STATIC_NUM 1
 #define RR_SHADOW_STATIC_DEN 2
@@ -1666,7 +1670,8 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DScen
     if ((gridDim.x & 7u) == 0u) blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
 #endif
     const uint32_t wave_id = blk * (RR_BLOCK / RR_WAVE) + threadIdx.x / RR_WAVE;
-    const uint32_t rounds = (uint32_t)(((unsigned long long)n_packets * RR_SHADOW_STATIC_NUM / RR_SHADOW_STATIC_DEN) / n_waves);
+    // (level 1's aligned packets cost much the same and are mostly dealt statically; the dense queue of the deeper levels keeps half dynamic)
+    const uint32_t rounds = (uint32_t)(((unsigned long long)n_packets * (FIXED ? RR_SHADOW_FIXED_STATIC_NUM : RR_SHADOW_STATIC_NUM) / (FIXED ? RR_SHADOW_FIXED_STATIC_DEN : RR_SHADOW_STATIC_DEN)) / n_waves);
     const uint32_t n_static = rounds * n_waves;
     uint32_t round = 0, dyn_next = 0, dyn_left = 0;
     // packets per fetch of the dynamic part: RR_DYN_FETCH on large launches (more costs locality: +4 % at 8, +10 % at 16), fewer when
