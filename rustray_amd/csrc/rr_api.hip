@@ -551,7 +551,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         dl[i].intensity = l.intensity; dl[i].max_angle = l.max_angle;
         dl[i].type = l.light_type | (l.enabled ? 0u : 0x80u);
         if (l.enabled) s->n_enabled_lights++;
-        if (s->n_enabled_lights > 32u) return fail(RR_ERR_UNSUPPORTED, "more than 32 enabled lights");
+        if (s->n_enabled_lights > RR_MAX_ENABLED_LIGHTS) return fail(RR_ERR_UNSUPPORTED, "more than %u enabled lights", RR_MAX_ENABLED_LIGHTS);
     }
     HIP_TRY(s->lights.reserve(std::max<size_t>(dl.size(), 1) * sizeof(DLight)));
     if (!dl.empty()) HIP_TRY(hipMemcpy(s->lights.p, dl.data(), dl.size() * sizeof(DLight), hipMemcpyHostToDevice));
