@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -569,21 +570,42 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     std::vector<DTriX> all_trix;
     std::vector<DTriAttr> all_attrs;
     std::vector<uint32_t> all_face_slot;
+    // the binary trees of the meshes are independent: built by a few host threads (a scene of 194 meshes / 559 k triangles:
+    // 0.4 s on one core), then collapsed and laid out one after the other
+    std::vector<rr::BvhResult> built(fs->n_meshes);
+    std::vector<char> built_ok(fs->n_meshes, 0);
+    {
+        std::atomic<uint32_t> next_mesh{0};
+        auto worker = [&]() {
+            for (;;) {
+                const uint32_t mi = next_mesh.fetch_add(1);
+                if (mi >= fs->n_meshes) break;
+                const rr_mesh& m = fs->meshes[mi];
+                const uint32_t nt = m.n_triangles;
+                std::vector<float> lo(3 * (size_t)nt), hi(3 * (size_t)nt);
+                for (uint32_t f = 0; f < nt; f++)
+                    for (int k = 0; k < 3; k++) {
+                        float a = m.positions[3 * (size_t)m.indices[3 * (size_t)f] + k];
+                        float b = m.positions[3 * (size_t)m.indices[3 * (size_t)f + 1] + k];
+                        float c = m.positions[3 * (size_t)m.indices[3 * (size_t)f + 2] + k];
+                        lo[3 * (size_t)f + k] = std::min(a, std::min(b, c));
+                        hi[3 * (size_t)f + k] = std::max(a, std::max(b, c));
+                    }
+                built_ok[mi] = rr::build_bvh(lo.data(), hi.data(), nt, RR_MAX_LEAF_TRIS, s->blas_depth_limit, &built[mi]) ? 1 : 0;
+            }
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const uint32_t n_threads = std::min<uint32_t>(std::min<uint32_t>(hw ? hw : 4u, 16u), std::max<uint32_t>(fs->n_meshes, 1u));
+        std::vector<std::thread> pool;
+        for (uint32_t t = 1; t < n_threads; t++) pool.emplace_back(worker);
+        worker();
+        for (std::thread& t : pool) t.join();
+    }
     for (uint32_t mi = 0; mi < fs->n_meshes; mi++) {
         const rr_mesh& m = fs->meshes[mi];
         uint32_t nt = m.n_triangles;
-        std::vector<float> lo(3 * (size_t)nt), hi(3 * (size_t)nt);
-        for (uint32_t f = 0; f < nt; f++)
-            for (int k = 0; k < 3; k++) {
-                float a = m.positions[3 * (size_t)m.indices[3 * (size_t)f] + k];
-                float b = m.positions[3 * (size_t)m.indices[3 * (size_t)f + 1] + k];
-                float c = m.positions[3 * (size_t)m.indices[3 * (size_t)f + 2] + k];
-                lo[3 * (size_t)f + k] = std::min(a, std::min(b, c));
-                hi[3 * (size_t)f + k] = std::max(a, std::max(b, c));
-            }
-        rr::BvhResult r;
-        if (!rr::build_bvh(lo.data(), hi.data(), nt, RR_MAX_LEAF_TRIS, s->blas_depth_limit, &r))
-            return fail(RR_ERR_UNSUPPORTED, "mesh %u: BVH depth limit exceeded", mi);
+        if (!built_ok[mi]) return fail(RR_ERR_UNSUPPORTED, "mesh %u: BVH depth limit exceeded", mi);
+        rr::BvhResult& r = built[mi];
         md[mi].tri_base = (uint32_t)all_tris.size();
         md[mi].n_tris = nt;
         md[mi].has_normals = m.n_normals > 0 && m.n_normal_faces > 0;
