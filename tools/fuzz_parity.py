@@ -171,6 +171,17 @@ def main():
                 ds.set_tuning(queue_budget_bytes=1, shade_chunk_rays=65536)
             out = ds.render(cam, cfg)
             st = ds.stats()
+            if seed % 5 == 0:   # the one-process multi-GPU entry over three handles of this device: region tiling, compact gather, de-interleave
+                others = [capi.DeviceScene(fs, 0) for _ in range(2)]
+                try:
+                    multi = capi.render_multi([ds] + others, cam, cfg)
+                finally:
+                    for o in others:
+                        o.close()
+                for k in ("rgba", "depth", "object_id"):
+                    if not np.array_equal(out[k], multi[k]):
+                        print("MULTI seed", seed, k, "differs from the single-handle frame")
+                        multi_bad = globals().get("multi_bad", 0) + 1
         def check(brute_force):
             ref = ob.render(fs.c_struct(), cam, cfg, n_threads=14, want_counters=True, brute_force=brute_force)
             r = compare_frames(out, ref)
