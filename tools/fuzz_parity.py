@@ -197,6 +197,8 @@ def main():
         if pixels_ok and not tree_ok:
             tree_only += 1
             print("RAY COUNTS seed", seed, {k: st[k] for k in ("primary_rays", "secondary_rays", "shaded_hits", "shadow_rays")}, {k: c[k] for k in ("rays_primary", "rays_secondary", "shaded_hits", "rays_shadow")})
+        if (seed - 99) % 250 == 0:
+            print(f"... {seed - 99} scenes, {bad} pixel mismatches so far, {time.time() - t0:.0f} s", flush=True)
         if not pixels_ok:
             bad += 1
             print("MISMATCH seed", seed, r, {k: st[k] for k in ("primary_rays", "secondary_rays", "shaded_hits", "shadow_rays")}, {k: c[k] for k in ("rays_primary", "rays_secondary", "shaded_hits", "rays_shadow")})
