@@ -804,7 +804,29 @@ RR_DEV bool trace_shadow_blockers(const DSceneView& sc, f3 o, f3 d, uint32_t dep
     return false;
 }
 
+// A non-finite shadow ray (a NaN normal puts the origin at NaN) in the reference: every candidate sphere reports Some(NaN)
+// (see trace_closest_nonfinite), triangles report nothing, the first sphere in (bbox distance, item) order is THE
+// intersection, and `in_light = toi > len` is false for a NaN toi -- the receiver is in shadow, for every kind of light
+// (src/raytracing.rs:884-892).  Its alpha map, if it has one, is then sampled at a NaN uv (a NaN texel under the
+// bilinear filter: the sample turns the pixel white).  Found by tools/fuzz_parity.py rich, seed 6601.
+RR_DEV void trace_shadow_nonfinite(const DSceneView& sc, f3 o, f3 d, uint32_t depth, float limit, ShadowSel* sel) {
+    sel->found = false; sel->within = false; sel->key = 0.0f; sel->item = -1; sel->t = 0.0f; sel->face = 0u;
+    for (int idx = 0; idx < (int)sc.n_items; idx++) {
+        const DItem& it = sc.items[idx];
+        const uint32_t flags = it.flags;
+        if (!(flags & RR_IF_SPHERE) || !item_passes(flags, true, depth)) continue;
+        LRay lr = inverse_ray(it, o, d, sc.general_w != 0u);
+        float key, tmin, t; bool inside;
+        if (!aabb_cast2(it.bmin, it.bmax, lr, false, &key, &tmin) || key != key) continue; // for_shadow forces solid = false
+        if (!ray_ball(it.radius, lr, false, &t, &inside)) continue;
+        if (!sel->found || key < sel->key || (key == sel->key && idx < sel->item)) {
+            sel->found = true; sel->key = key; sel->item = idx; sel->t = t; sel->within = !(t > limit);
+        }
+    }
+}
+
 RR_DEV void trace_shadow_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, float limit, int* s_stack, ShadowSel* sel) {
+    if (ray_nonfinite(o, d)) { trace_shadow_nonfinite(sc, o, d, depth, limit, sel); return; }
     sel->found = false; sel->within = false; sel->key = 0.0f; sel->item = -1; sel->t = 0.0f; sel->face = 0u;
     // an item whose world box starts beyond the light, or beyond the selected item's key, cannot matter
 #define RR_SHADOW_BOUND (sel->found ? fminf(limit, sel->key * 1.00001f + 1e-6f) : limit)

@@ -141,7 +141,7 @@ def test_deep_mesh_tree_keeps_within_the_traversal_stack(hip, oracle):
     assert (out["object_id"] == 2).sum() > 1000
 
 
-@pytest.mark.parametrize("name", ["fuzz_alpha", "fuzz_234", "fuzz_568"])
+@pytest.mark.parametrize("name", ["fuzz_alpha", "fuzz_234", "fuzz_568", "fuzz_6601"])
 def test_non_finite_samples_reach_the_pixel_as_in_the_reference(hip, oracle, name):
     """Scenes reduced from tools/fuzz_parity.py mismatches (tests/golden/fuzz_*.npz).  The reference's f32 sums carry a
     NaN sample to the pixel (NaN.min(1.0) = 1.0 -> 255, src/raytracing.rs:406-417): fixed-point sums cannot, so k_shade /
@@ -149,7 +149,10 @@ def test_non_finite_samples_reach_the_pixel_as_in_the_reference(hip, oracle, nam
       fuzz_alpha: a sphere with flipped normals shadowed by a mesh with an alpha map.  The light term is exactly 0, but the
                   map is sampled at the RECEIVER's uv of the occluder's hit point (:905): acos(> 1) = NaN, 0 * NaN = NaN;
       fuzz_234:   a reflectivity map sampled at a NaN uv at a sphere's pole, no light: color * (1 - NaN) with color = 0;
-      fuzz_568:   several such items, semi-transparent and invisible ones, refraction index below 1."""
+      fuzz_568:   several such items, semi-transparent and invisible ones, refraction index below 1;
+      fuzz_6601:  a normal map gives a sphere a NaN normal, the SHADOW ray starts at NaN: in the reference every candidate
+                  sphere then reports Some(NaN), `in_light = toi > len` is false, and the occluder's alpha map sampled at a
+                  NaN uv under the bilinear filter makes the attenuation NaN (rr_kernels.hip: trace_shadow_nonfinite)."""
     from rustray_amd.flat import FlatScene
     import os
     from tests.helpers import GOLDEN
