@@ -2,7 +2,7 @@
 """Developer tool: HIP path against the oracle on N seeded random scenes (the generator of tests/test_gpu_random.py) with
 random frame sizes, sample counts (up to 64), recursion depths (up to 9), fog / gamma / depth of field, and with the
 binning and small-arena paths switched on for some seeds.  Counts frames that differ by more than 1 LSB or whose path
-trees differ.  usage (on the GPU box): python tools/fuzz_parity.py [N] [basic|rich|far|farbasic]"""
+trees differ.  usage (on the GPU box): python tools/fuzz_parity.py [N] [basic|rich|far|farbasic] [first seed]"""
 import sys, time
 sys.path.insert(0, '.')
 import torch  # noqa
@@ -160,7 +160,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     bad = tree_only = 0
     t0 = time.time()
-    for seed in range(100, 100 + n):
+    start = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+    for seed in range(start, start + n):
         fs, w, h, kw, brute, _ = case(seed, mode)
         cam = camera_for(fs, w, h).c_struct()
         cfg = make_config(**kw)
@@ -197,8 +198,8 @@ def main():
         if pixels_ok and not tree_ok:
             tree_only += 1
             print("RAY COUNTS seed", seed, {k: st[k] for k in ("primary_rays", "secondary_rays", "shaded_hits", "shadow_rays")}, {k: c[k] for k in ("rays_primary", "rays_secondary", "shaded_hits", "rays_shadow")})
-        if (seed - 99) % 250 == 0:
-            print(f"... {seed - 99} scenes, {bad} pixel mismatches so far, {time.time() - t0:.0f} s", flush=True)
+        if (seed - start + 1) % 250 == 0:
+            print(f"... {seed - start + 1} scenes, {bad} pixel mismatches so far, {time.time() - t0:.0f} s", flush=True)
         if not pixels_ok:
             bad += 1
             print("MISMATCH seed", seed, r, {k: st[k] for k in ("primary_rays", "secondary_rays", "shaded_hits", "shadow_rays")}, {k: c[k] for k in ("rays_primary", "rays_secondary", "shaded_hits", "rays_shadow")})
