@@ -195,6 +195,10 @@ def main():
             print("NOTE seed", seed, "differs from the oracle's item-tree form only" if pixels_ok else "differs from both oracle forms")
         tree_ok = (st["primary_rays"] == c["rays_primary"] and st["secondary_rays"] == c["rays_secondary"] and st["shaded_hits"] == c["shaded_hits"]
                    and st["shadow_rays"] <= c["rays_shadow"])
+        if pixels_ok and not tree_ok and not brute and mode in ("far", "farbasic"):
+            r, c, pixels_ok = check(True)   # (D10 again: the oracle's item tree drops candidates far from the origin; the all-items form decides)
+            tree_ok = (st["primary_rays"] == c["rays_primary"] and st["secondary_rays"] == c["rays_secondary"] and st["shaded_hits"] == c["shaded_hits"]
+                       and st["shadow_rays"] <= c["rays_shadow"])
         if pixels_ok and not tree_ok:
             tree_only += 1
             print("RAY COUNTS seed", seed, {k: st[k] for k in ("primary_rays", "secondary_rays", "shaded_hits", "shadow_rays")}, {k: c[k] for k in ("rays_primary", "rays_secondary", "shaded_hits", "rays_shadow")})
