@@ -64,11 +64,13 @@ RR_DEV LRay inverse_ray(const DItem& it, f3 o, f3 d, bool general_w) {
     r.d = mk3(row4(it.inv0, d.x, d.y, d.z, 0.0f), row4(it.inv1, d.x, d.y, d.z, 0.0f), row4(it.inv2, d.x, d.y, d.z, 0.0f));
     return r;
 }
+// (the w of an affine inverse is ((0 x + 0 y) + 0 z) + 1: exactly 1 for a finite point, NaN for any other -- 0 times an
+// infinity -- so a non-finite point always takes the dividing form, and comes out NaN in every component as in the reference)
 RR_DEV f3 to_local_point(const DItem& it, f3 p, bool general_w) {
     float x = row4(it.inv0, p.x, p.y, p.z, 1.0f);
     float y = row4(it.inv1, p.x, p.y, p.z, 1.0f);
     float z = row4(it.inv2, p.x, p.y, p.z, 1.0f);
-    if (general_w) { float w = row4(it.inv3, p.x, p.y, p.z, 1.0f); x = x / w; y = y / w; z = z / w; }
+    if (general_w || ((p.x - p.x) + (p.y - p.y)) + (p.z - p.z) != 0.0f) { float w = row4(it.inv3, p.x, p.y, p.z, 1.0f); x = x / w; y = y / w; z = z / w; }
     return mk3(x, y, z);
 }
 RR_DEV f3 to_world_normal(const DItem& it, f3 n) {
@@ -614,7 +616,7 @@ RR_DEV void trace_closest_nonfinite(const DSceneView& sc, f3 o, f3 d, uint32_t d
         const DItem& it = rr_global(sc.items)[idx];
         const uint32_t flags = it.flags;
         if (!(flags & RR_IF_SPHERE) || !item_passes(flags, false, depth)) continue;
-        LRay lr = inverse_ray(it, o, d, sc.general_w != 0u);
+        LRay lr = inverse_ray(it, o, d, true); // (w is NaN for a non-finite origin: see to_local_point)
         float key, t; bool inside;
         if (!aabb_cast(it.bmin, it.bmax, lr, (flags & RR_IF_SOLID_BASE) != 0u, &key) || key != key) continue;
         if (!ray_ball(it.radius, lr, (flags & RR_IF_SOLID_BASE) != 0u, &t, &inside)) continue;
@@ -815,7 +817,7 @@ RR_DEV void trace_shadow_nonfinite(const DSceneView& sc, f3 o, f3 d, uint32_t de
         const DItem& it = sc.items[idx];
         const uint32_t flags = it.flags;
         if (!(flags & RR_IF_SPHERE) || !item_passes(flags, true, depth)) continue;
-        LRay lr = inverse_ray(it, o, d, sc.general_w != 0u);
+        LRay lr = inverse_ray(it, o, d, true); // (w is NaN for a non-finite origin: see to_local_point)
         float key, tmin, t; bool inside;
         if (!aabb_cast2(it.bmin, it.bmax, lr, false, &key, &tmin) || key != key) continue; // for_shadow forces solid = false
         if (!ray_ball(it.radius, lr, false, &t, &inside)) continue;
@@ -1398,7 +1400,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
         DTriAttr at; float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f; bool have_weights = false;
         at.s0 = at.s1 = at.s2 = at.s3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (it_flags & RR_IF_SPHERE) {
-            LRay lr = inverse_ray(it, ro, rd, gw);
+            LRay lr = inverse_ray(it, ro, rd, gw || ray_nonfinite(ro, rd)); // (see to_local_point)
             float t2 = 0.0f; bool inside = false;
             ray_ball(it.radius, lr, (it_flags & RR_IF_SOLID_BASE) != 0u, &t2, &inside);
             f3 nl = normalize3(lr.o + lr.d * t2);
