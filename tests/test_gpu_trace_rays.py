@@ -110,6 +110,41 @@ def test_camera_far_outside_the_scene_and_back(hip, oracle):
         assert res["n_rgb_over"] == 0 and res["n_id_diff"] == 0 and res["nan_mismatch"] == 0, res
 
 
+def test_random_rays_with_special_values_hit_the_same_things(hip, oracle):
+    """tools/fuzz_rays.py in small: random rays into the fuzzer's rich scenes, a third with NaN components, infinite origin
+    components, signed zeros or denormals, against the oracle's all-items form -- bit for bit (a NaN toi as NaN).  A point
+    with a non-finite component takes the DIVIDING form of the inverse transform even for an affine inverse."""
+    from tools.fuzz_parity import rich_scene
+    special_o = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-42, -1e-42, 1.0], np.float32)
+    special_d = np.array([np.nan, 0.0, -0.0, 1e-42, -1e-42, 1.0], np.float32)
+    n_special_found = 0
+    for seed in range(390, 400):
+        fs = rich_scene(9000 + seed)
+        rng = np.random.default_rng(seed)
+        n = 1200
+        eye = np.asarray(fs.meta["camera"]["eye_pos"], np.float32)
+        o = (eye[None, :] + rng.normal(size=(n, 3)).astype(np.float32) * np.float32(rng.choice([0.01, 1.0, 5.0]))).astype(np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        d[: n // 2] /= np.linalg.norm(d[: n // 2], axis=1, keepdims=True)
+        for i in range(n // 3):
+            for _ in range(int(rng.integers(1, 4))):
+                if rng.random() < 0.5:
+                    o[i, int(rng.integers(0, 3))] = special_o[int(rng.integers(0, len(special_o)))]
+                else:
+                    d[i, int(rng.integers(0, 3))] = special_d[int(rng.integers(0, len(special_d)))]
+        depth = int(rng.integers(1, 3))
+        with hip.DeviceScene(fs, 0) as ds:
+            g = ds.trace_rays(o, d, depth)
+        r = oracle.trace_rays(fs.c_struct(), o, d, depth, brute_force=True)
+        assert np.array_equal(g[0], r[0]), seed
+        f = g[0]
+        assert np.array_equal(g[1][f], r[1][f]) and np.array_equal(g[2][f], r[2][f]), seed
+        same = (g[3][f].view(np.uint32) == r[3][f].view(np.uint32)) | (np.isnan(g[3][f]) & np.isnan(r[3][f]))
+        assert same.all(), seed
+        n_special_found += int(np.isnan(g[3][f]).sum())
+    assert n_special_found > 0      # NaN hits (non-finite rays against spheres) did occur
+
+
 def test_trace_rays_argument_checks(hip):
     fs = load_scene("spheres")
     with hip.DeviceScene(fs, 0) as ds:
