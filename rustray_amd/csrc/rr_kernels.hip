@@ -34,6 +34,13 @@
 #ifndef RR_DYN_FETCH
 #define RR_DYN_FETCH 4
 #endif
+// An item's REPORTED toi can lie in front of its box.  ray_toi_with_ball takes the root of b^2 - a c, which cancels
+// catastrophically when the origin is far from the sphere: the discriminant of a grazing ray is rounding noise of the order
+// u b^2, and the reported toi is off by up to sqrt(u) ~ 2.4e-4 of the distance (a sphere 2e4 units away "hit" 7 units in
+// front of its box, by a ray that misses it: tools/fuzz_rays.py far, seed 419).  Wherever the top level prunes by distance
+// -- against the best hit, or against the light -- the bound is therefore taken 1e-3 wider than the box distance says
+// (and kept finite: the unused child slots of a node are boxes at infinity, which only a finite bound rejects).
+#define RR_TOI_SLACK 1.001f
 #ifndef RR_SHADOW_FIXED_STATIC_NUM
 #define RR_SHADOW_FIXED_STATIC_NUM 7 // level 1 (fixed slots): sponza_syn shadow 6.3 -> 6.0 ms against one half
 #define RR_SHADOW_FIXED_STATIC_DEN 8
@@ -590,7 +597,7 @@ RR_DEV void trace_closest_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, 
     // while-while: every lane walks the top level until it holds a candidate item (or is done), so the per-mesh
     // walks below run with the lanes of the wave together instead of one straggler at a time
     for (;;) {
-        while (cur >= 0) { RR_NODE4_STEP(sc.tnodes4, ws, best->t) }
+        while (cur >= 0) { RR_NODE4_STEP(sc.tnodes4, ws, fminf(best->t * RR_TOI_SLACK, RR_FLT_MAX)) }
         if (cur == RR_SENTINEL) break;
         closest_item(sc, (int)RR_LEAF_FIRST((uint32_t)~cur), o, d, depth, s_stack, sp, best); // one item per top-level leaf
         sp--; cur = STK(sp);
@@ -697,7 +704,7 @@ RR_DEV bool beam_candidates(const DSceneView& sc, f3 o, f3 d, float far, int* s_
             beam_axis(negz, lo.z, hi.z, ozl, ozh, azl, azh, &tnz, &tfz);
             const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
             const float tf = fminf(fminf(tfx, tfy), tfz);
-            key = tn * 0.99999f;
+            key = tn * (1.0f / RR_TOI_SLACK) * 0.99999f; // a lower bound on any toi the item can report
             cand = key <= tf * 1.00001f && key <= far;
         }
         const unsigned long long m = __ballot(cand);
@@ -753,7 +760,7 @@ RR_DEV void shadow_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t dept
     // An item whose box starts beyond the light can never be hit within the light distance; it is skipped in this
     // pass.  It can still matter as a BLOCKER (hit, ordered before the occluder found here): trace_shadow_ray
     // runs a second pass for exactly that case.
-    if (tmin > limit) return;
+    if (tmin > limit * RR_TOI_SLACK) return;
     if (sel->found && !(key < sel->key || (key == sel->key && idx < sel->item))) return;
     bool any = false, within = false; float t = 0.0f; uint32_t face = 0u;
     if (flags & RR_IF_SPHERE) {
@@ -782,7 +789,7 @@ RR_DEV bool shadow_blocker_item(const DSceneView& sc, int idx, f3 o, f3 d, uint3
     LRay lr = inverse_ray(it, o, d, sc.general_w != 0u);
     float key, tmin;
     if (!aabb_cast2(it.bmin, it.bmax, lr, false, &key, &tmin)) return false;
-    if (key != key || !(tmin > limit)) return false;
+    if (key != key || !(tmin > limit * RR_TOI_SLACK)) return false;
     if (!(key < sel.key || (key == sel.key && idx < sel.item))) return false;
     if (flags & RR_IF_SPHERE) { float t; bool inside; return ray_ball(it.radius, lr, false, &t, &inside); }
     if (it.n_tris == 0u) return false;
@@ -831,7 +838,7 @@ RR_DEV void trace_shadow_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, f
     if (ray_nonfinite(o, d)) { trace_shadow_nonfinite(sc, o, d, depth, limit, sel); return; }
     sel->found = false; sel->within = false; sel->key = 0.0f; sel->item = -1; sel->t = 0.0f; sel->face = 0u;
     // an item whose world box starts beyond the light, or beyond the selected item's key, cannot matter
-#define RR_SHADOW_BOUND (sel->found ? fminf(limit, sel->key * 1.00001f + 1e-6f) : limit)
+#define RR_SHADOW_BOUND fminf(sel->found ? fminf(limit * RR_TOI_SLACK, sel->key * 1.00001f + 1e-6f) : limit * RR_TOI_SLACK, RR_FLT_MAX)
     const Slab4 ws = make_slab4(make_slab(o, d), 0u);
     int sp = 1;
     STK(0) = RR_SENTINEL;

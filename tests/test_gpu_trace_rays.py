@@ -110,20 +110,27 @@ def test_camera_far_outside_the_scene_and_back(hip, oracle):
         assert res["n_rgb_over"] == 0 and res["n_id_diff"] == 0 and res["nan_mismatch"] == 0, res
 
 
-def test_random_rays_with_special_values_hit_the_same_things(hip, oracle):
+@pytest.mark.parametrize("far", [False, True])
+def test_random_rays_with_special_values_hit_the_same_things(hip, oracle, far):
     """tools/fuzz_rays.py in small: random rays into the fuzzer's rich scenes, a third with NaN components, infinite origin
     components, signed zeros or denormals, against the oracle's all-items form -- bit for bit (a NaN toi as NaN).  A point
     with a non-finite component takes the DIVIDING form of the inverse transform even for an affine inverse."""
-    from tools.fuzz_parity import rich_scene
+    from tools.fuzz_parity import rich_scene, far_and_scaled
     special_o = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-42, -1e-42, 1.0], np.float32)
     special_d = np.array([np.nan, 0.0, -0.0, 1e-42, -1e-42, 1.0], np.float32)
     n_special_found = 0
-    for seed in range(390, 400):
+    # far: the scenes moved up to 1e8 from the origin and scaled by up to 1e4.  Seed 419 holds a ray that starts 2e4 units from a
+    # sphere, grazes past it, and "hits" it in the reference 7 units in FRONT of its box: the discriminant of ray_toi_with_ball is
+    # rounding noise there, so the top level must not prune by distance more tightly than sqrt(u) (RR_TOI_SLACK).
+    for seed in (range(412, 422) if far else range(390, 400)):
         fs = rich_scene(9000 + seed)
+        scale = 1.0
+        if far:
+            fs, scale = far_and_scaled(fs, seed)
         rng = np.random.default_rng(seed)
-        n = 1200
+        n = 3000 if far else 1200
         eye = np.asarray(fs.meta["camera"]["eye_pos"], np.float32)
-        o = (eye[None, :] + rng.normal(size=(n, 3)).astype(np.float32) * np.float32(rng.choice([0.01, 1.0, 5.0]))).astype(np.float32)
+        o = (eye[None, :] + rng.normal(size=(n, 3)).astype(np.float32) * np.float32(rng.choice([0.01, 1.0, 5.0]) * scale)).astype(np.float32)
         d = rng.normal(size=(n, 3)).astype(np.float32)
         d[: n // 2] /= np.linalg.norm(d[: n // 2], axis=1, keepdims=True)
         for i in range(n // 3):
@@ -142,7 +149,7 @@ def test_random_rays_with_special_values_hit_the_same_things(hip, oracle):
         same = (g[3][f].view(np.uint32) == r[3][f].view(np.uint32)) | (np.isnan(g[3][f]) & np.isnan(r[3][f]))
         assert same.all(), seed
         n_special_found += int(np.isnan(g[3][f]).sum())
-    assert n_special_found > 0      # NaN hits (non-finite rays against spheres) did occur
+    assert far or n_special_found > 0      # NaN hits (non-finite rays against spheres) did occur
 
 
 def test_trace_rays_argument_checks(hip):

@@ -1,17 +1,18 @@
 #!/usr/bin/env python3
 """Developer tool: rr_trace_rays against the oracle's Raytracing::trace on random rays into random scenes, a third of them
 with special values in some components (NaN, infinite origin components, +-0, denormals): found / item / face id / toi must agree bit
-for bit (a NaN toi as NaN).  usage (on the GPU box): python tools/fuzz_rays.py [scenes] [first seed]"""
+for bit (a NaN toi as NaN).  usage (on the GPU box): python tools/fuzz_rays.py [scenes] [first seed] [far]"""
 import sys, time
 sys.path.insert(0, '.')
 import torch  # noqa
 import numpy as np
 from oracle import binding as ob
 from rustray_amd import capi
-from tools.fuzz_parity import rich_scene
+from tools.fuzz_parity import rich_scene, far_and_scaled
 
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+FAR = len(sys.argv) > 3 and sys.argv[3] == "far"   # the scenes moved far from the origin and scaled (fuzz_parity's far mode)
 # Special values as a render can produce them: NaN anywhere (a NaN normal), an infinite ORIGIN component (a hit point that overflowed),
 # zeros and denormals.  Not covered, and not claimed: infinite DIRECTION components (directions are normalised vectors or their
 # reflections: a triangle then reports toi = t * (1 / inf) = 0 in the reference, which the non-finite path here does not reproduce) and
@@ -22,10 +23,13 @@ bad = 0
 t0 = time.time()
 for seed in range(first, first + n_scenes):
     fs = rich_scene(9000 + seed)
+    scale = 1.0
+    if FAR:
+        fs, scale = far_and_scaled(fs, seed)
     rng = np.random.default_rng(seed)
     n = 3000
     eye = np.asarray(fs.meta["camera"]["eye_pos"], np.float32)
-    o = (eye[None, :] + rng.normal(size=(n, 3)).astype(np.float32) * np.float32(rng.choice([0.01, 1.0, 5.0]))).astype(np.float32)
+    o = (eye[None, :] + rng.normal(size=(n, 3)).astype(np.float32) * np.float32(rng.choice([0.01, 1.0, 5.0]) * scale)).astype(np.float32)
     d = rng.normal(size=(n, 3)).astype(np.float32)
     d[: n // 2] /= np.linalg.norm(d[: n // 2], axis=1, keepdims=True)          # half normalised, half not (trace does not normalise)
     k = n // 3                                                                 # special values in one to three components of the first third
