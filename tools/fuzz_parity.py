@@ -2,7 +2,7 @@
 """Developer tool: HIP path against the oracle on N seeded random scenes (the generator of tests/test_gpu_random.py) with
 random frame sizes, sample counts (up to 64), recursion depths (up to 9), fog / gamma / depth of field, and with the
 binning and small-arena paths switched on for some seeds.  Counts frames that differ by more than 1 LSB or whose path
-trees differ.  usage (on the GPU box): python tools/fuzz_parity.py [N] [basic|rich|far|farbasic] [first seed]"""
+trees differ.  usage (on the GPU box): python tools/fuzz_parity.py [N] [basic|rich|far|farbasic|tele|telebasic] [first seed]"""
 import sys, time
 sys.path.insert(0, '.')
 import torch  # noqa
@@ -132,18 +132,34 @@ def far_and_scaled(fs, seed):
     return fs, s
 
 
+def tele(fs, seed):
+    """The same scene through a long lens: the camera moved back by 1e2 .. 1e4 scene sizes along its view direction, the field of
+    view narrowed by as much.  Every distance along a ray is then huge against the scene, which is where the reference's sphere
+    test turns into rounding noise (RR_TOI_SLACK) and the top level may not prune by distance too tightly."""
+    rng = np.random.default_rng(seed + 33)
+    f = float(rng.choice([1e2, 1e3, 1e4]))
+    c = fs.meta["camera"]
+    d = np.asarray(c["dir"], np.float64); d /= np.linalg.norm(d)
+    c["eye_pos"] = [float(np.float32(v)) for v in (np.asarray(c["eye_pos"], np.float64) - d * 10.0 * f)]
+    c["fov"] = float(c["fov"]) / f
+    c["clipping_far"] = float(c["clipping_far"]) + 20.0 * f
+    return fs, f
+
+
 def case(seed, mode):
     """The scene, frame size, config keywords and oracle mode of one fuzz seed."""
-    fs = rich_scene(9000 + seed) if mode in ("rich", "far") else _random_scene(5000 + seed)
+    fs = rich_scene(9000 + seed) if mode in ("rich", "far", "tele") else _random_scene(5000 + seed)
     scale = 1.0
     if mode in ("far", "farbasic"):
         fs, scale = far_and_scaled(fs, seed)
+    if mode in ("tele", "telebasic"):
+        fs, scale = tele(fs, seed)
     rng = np.random.default_rng(seed)
     w, h = int(rng.integers(40, 110)), int(rng.integers(30, 90))
     kw = dict(samples=int(rng.choice([1, 2, 3, 4, 6, 16, 64])), monte_carlo=bool(seed % 3), seed=seed, max_recursion=int(rng.choice([1, 2, 4, 6, 9])),
               fog_density=float(rng.choice([0.0, 0.02])), gamma_correction=bool(seed % 5 == 0),
               aperture_size=float(rng.choice([1.0, 1.0, 8.0])), focal_length=float(rng.choice([1.0, 6.0])))
-    brute = mode in ("far", "farbasic") and seed % 2 == 0
+    brute = mode in ("far", "farbasic", "tele", "telebasic") and seed % 2 == 0
     return fs, w, h, kw, brute, scale
 
 
@@ -188,14 +204,14 @@ def main():
             r = compare_frames(out, ref)
             return r, ref["counters"], r["n_rgb_over"] == 0 and r["n_id_diff"] == 0 and r["nan_mismatch"] == 0 and depth_ok(out["depth"], ref["depth"])
         r, c, pixels_ok = check(brute)
-        if not pixels_ok and not brute and mode in ("far", "farbasic"):
+        if not pixels_ok and not brute and mode in ("far", "farbasic", "tele", "telebasic"):
             # the oracle's own item tree stands in for the `bvh` crate's (absent dependency) and tests unpadded f32 boxes: where float
             # spacing is a thousandth of the scene it drops candidates the item-space test accepts.  The all-items form decides.
             r, c, pixels_ok = check(True)
             print("NOTE seed", seed, "differs from the oracle's item-tree form only" if pixels_ok else "differs from both oracle forms")
         tree_ok = (st["primary_rays"] == c["rays_primary"] and st["secondary_rays"] == c["rays_secondary"] and st["shaded_hits"] == c["shaded_hits"]
                    and st["shadow_rays"] <= c["rays_shadow"])
-        if pixels_ok and not tree_ok and not brute and mode in ("far", "farbasic"):
+        if pixels_ok and not tree_ok and not brute and mode in ("far", "farbasic", "tele", "telebasic"):
             r, c, pixels_ok = check(True)   # (D10 again: the oracle's item tree drops candidates far from the origin; the all-items form decides)
             tree_ok = (st["primary_rays"] == c["rays_primary"] and st["secondary_rays"] == c["rays_secondary"] and st["shaded_hits"] == c["shaded_hits"]
                        and st["shadow_rays"] <= c["rays_shadow"])
