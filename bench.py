@@ -20,6 +20,13 @@ Extra keys (rank 0, N = 1): `rgba_only_ms` (aux buffers not requested), `rr_rend
 (the same frame through rr_render into host memory, PCIe included), and `other_configs`
 (helmet_syn 1280x720x64, lotus_syn 1280x720x512 + DOF: stand-ins for BASELINE configs C3 / C5).
 
+N > 1 additionally reports what shows that RCCL really saw N ranks (`dist_backend`, `world_size` as torch.distributed
+reports it, every rank's device), `frame_checksum_matches_single_gpu` (rank 0 renders the whole frame alone after the
+timed region and compares), `gather_ms` / `render_only_ms` (timed apart, after the timed region), and `one_process`:
+the same frame through rr_render_multi over the same N devices from ONE host process (the form the reference host is,
+src/renderer.rs:105-172), run by a helper process that rank 0 starts before it touches the GPU.  `--one-process` runs
+that form alone.
+
 Rank 0 prints ONE JSON line with `roofline` and `cpu_baseline` (the C++ restatement in
 oracle/ timed on the host cores over a bounded sample of the same frame).
 
@@ -162,6 +169,88 @@ def extras(args, ds, camc, cfg, step, fence):
     return out
 
 
+def one_process_main(args):
+    """rr_render_multi over --gpus devices from ONE host process (no torch, no torch.distributed): one handle per device,
+    one host thread per device inside the call, peer-to-peer copies into device 0, one host copy.  As a helper of an N-rank
+    run it builds everything, then waits for "go" on stdin so that the N ranks are idle while it is timed."""
+    from rustray_amd import capi
+    n = args.gpus
+    n_dev = capi.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py --one-process needs a GPU")
+    devices = [0] * n if args.same_device else list(range(n))
+    if max(devices) >= n_dev:
+        print(json.dumps({"error": f"{n} devices asked, {n_dev} visible"}), flush=True)
+        return
+    fs, cam, cfg = build_workload(args.scene, args.width, args.height, args.spp, args.monte_carlo)
+    camc = cam.c_struct()
+    scenes = [capi.DeviceScene(fs, d) for d in devices]
+    try:
+        if args.one_process_helper:
+            line = sys.stdin.readline()
+            if line.strip() != "go":
+                return
+        for _ in range(max(args.warmup, 1)):
+            capi.render_multi(scenes, camc, cfg, aux=not args.rgba_only)
+        t0 = time.perf_counter()
+        rays = 0
+        for _ in range(args.steps):
+            out = capi.render_multi(scenes, camc, cfg, aux=not args.rgba_only)
+            for ds in scenes:
+                st = ds.stats()
+                rays += st["primary_rays"] + st["secondary_rays"] + st["shadow_rays"]
+        elapsed = time.perf_counter() - t0
+        st0 = scenes[0].stats()
+        res = {"metric": "Mrays/s", "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": max(args.warmup, 1),
+               "ms_per_step": elapsed * 1000.0 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic", "config": {"workload": f"{fs.name} {args.width}x{args.height} {args.spp}spp monte_carlo={args.monte_carlo} max_recursion=6",
+                                               "form": "rr_render_multi: ONE host process, one handle and one host thread per device, frame into host memory (PCIe included)",
+                                               "devices": devices},
+               "frame_checksum": int(out["rgba"].astype(np.int64).sum()),
+               "multi_devices": st0["multi_devices"], "multi_peer_links": st0["multi_peer_links"], "multi_staged_links": st0["multi_staged_links"],
+               "ms_multi_exchange": st0["ms_multi_exchange"], "source_id": capi.source_id()}
+        print(json.dumps(res), flush=True)
+    finally:
+        for ds in scenes:
+            ds.close()
+
+
+def start_one_process_helper(args, world):
+    """Started by rank 0 BEFORE it initialises the GPU (a process that has may not exec another program)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--one-process-helper", "--gpus", str(world), "--steps", str(max(1, min(args.steps, 5))),
+           "--warmup", "1", "--scene", args.scene, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp),
+           "--monte-carlo", str(args.monte_carlo)]
+    if args.rgba_only:
+        cmd.append("--rgba-only")
+    if args.dist_backend == "gloo":
+        cmd.append("--same-device")   # rehearsal: the ranks share a card
+    try:
+        return subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    except OSError as e:
+        return e
+
+
+def finish_one_process_helper(helper, timeout=300):
+    """Rank 0, after the timed region (the other ranks wait at a barrier): let the helper run its frames, return its line."""
+    import subprocess
+    if not hasattr(helper, "communicate"):
+        return {"error": f"helper did not start: {helper}"}
+    try:
+        out, err = helper.communicate("go\n", timeout=timeout)
+    except subprocess.TimeoutExpired:
+        helper.kill()   # this exact child, by handle
+        helper.communicate()
+        return {"error": f"rr_render_multi helper did not finish within {timeout} s"}
+    lines = [ln for ln in out.strip().splitlines() if ln.startswith("{")]
+    if not lines:
+        return {"error": "no result line", "stderr_tail": err[-400:]}
+    try:
+        return json.loads(lines[-1])
+    except ValueError:
+        return {"error": "unparsable result line", "stdout_tail": out[-400:]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,7 +268,13 @@ def main():
     ap.add_argument("--binning", action="store_true", help="developer A/B: bin deeper levels by (origin cell, direction octant) before tracing")
     ap.add_argument("--tile", default="32x8")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
+    ap.add_argument("--one-process", action="store_true", help="time rr_render_multi over --gpus devices from this ONE process (no torch.distributed)")
+    ap.add_argument("--same-device", action="store_true", help="--one-process rehearsal: all handles on device 0")
+    ap.add_argument("--no-one-process", action="store_true", help="N > 1: skip the rr_render_multi leg")
+    ap.add_argument("--one-process-helper", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.one_process or args.one_process_helper:
+        return one_process_main(args)
 
     import torch
     import torch.distributed as dist
@@ -189,6 +284,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # the one-process leg runs in a helper that must exist BEFORE this process touches the GPU (a GPU process may not exec)
+    helper = start_one_process_helper(args, world) if (world > 1 and rank == 0 and not args.no_one_process) else None
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -210,10 +307,11 @@ def main():
     if args.binning:
         ds.set_tuning(bin_min_rays=1 << 18)
     camc = cam.c_struct()
+    via_cpu = args.dist_backend == "gloo"
 
     def step(aux=not args.rgba_only):
-        parts = render_region_torch(ds, camc, cfg, tf, aux=aux)
-        return tf.gather(parts, use_device_kernel=True, via_cpu=(args.dist_backend == "gloo"))
+        parts = render_region_torch(ds, camc, cfg, tf, aux=aux, via_cpu=via_cpu)   # into the rank's persistent pack buffer
+        return tf.gather(parts, use_device_kernel=True, via_cpu=via_cpu)
 
     def fence():
         if world > 1:
@@ -245,6 +343,37 @@ def main():
     elapsed = float(tmax.item())
     primary, secondary, shadow, shaded = [float(v) for v in work.tolist()]
     rays = primary + secondary + shadow
+
+    # ---- N > 1, outside the timed region: what shows the collective really ran over N ranks, and the gather timed apart
+    dist_info = None
+    if world > 1:
+        me = {"rank": rank, "local_rank": local_rank, "device_index": torch.cuda.current_device(),
+              "device": torch.cuda.get_device_name(torch.cuda.current_device()), "pid": os.getpid(), "region_pixels": tf.n_pixels()}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+        t_render = t_gather = 0.0
+        reps = 3
+        for _ in range(reps):
+            fence()
+            t0 = time.perf_counter()
+            parts = render_region_torch(ds, camc, cfg, tf, aux=not args.rgba_only, via_cpu=via_cpu)
+            fence()
+            t1 = time.perf_counter()
+            tf.gather(parts, use_device_kernel=True, via_cpu=via_cpu)
+            fence()
+            t_render += t1 - t0
+            t_gather += time.perf_counter() - t1
+        tt = torch.tensor([t_render, t_gather], dtype=torch.float64, device=rdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist_info = {"dist_backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": everyone,
+                     "render_only_ms": float(tt[0]) * 1000.0 / reps, "gather_ms": float(tt[1]) * 1000.0 / reps,
+                     "gather_bytes_per_rank": int(tf._pack.numel())}
+        if rank == 0:   # the same frame on this rank's GPU alone: the tiled frame must be bit-identical to it
+            whole = ds.render(camc, cfg, aux=False)
+            dist_info["frame_checksum_single_gpu"] = int(whole["rgba"].astype(np.int64).sum())
+            if helper is not None:
+                dist_info["one_process"] = finish_one_process_helper(helper)
+        dist.barrier()
 
     if rank == 0:
         ms_per_step = elapsed * 1000.0 / args.steps
@@ -283,7 +412,13 @@ def main():
             roof = {"bound": "valu_issue", "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "kernel": "k_trace_closest<true>", "launches": launches,
                     "avg_launch_ms": avg_ms, "rays_per_launch": rays_per_launch, "achieved": None, "frac": None, "traffic": None}
             k1 = (sq or {}).get("kernels", {}).get("k_trace_closest<true>")
-            if k1 and sq.get("workload", "").startswith(f"{fs.name} {args.width}x{args.height} {args.spp}spp"):
+            same_workload = bool(k1) and sq.get("workload", "").startswith(f"{fs.name} {args.width}x{args.height} {args.spp}spp")
+            same_build = bool(sq) and sq.get("source_id") == capi.source_id()
+            if k1 and not (same_workload and same_build):
+                # the instruction count is a property of code + scene: a count taken from another build or workload is not mixed with this run's time
+                roof["frac_reason"] = (f"{sq_path} was collected on source_id {sq.get('source_id')} / workload {sq.get('workload', '')[:40]!r}; "
+                                       f"this run is source_id {capi.source_id()}: re-run tools/profile_round.sh")
+            if k1 and same_workload and same_build:
                 vpr = k1["valu_insts_per_ray"]
                 roof["achieved"] = vpr * rays_per_launch / (avg_ms * 1e-3) / 1e9
                 roof["frac"] = roof["achieved"] / VALU_PEAK_GINST
@@ -311,6 +446,10 @@ def main():
                                          "frame_device_ms": acc["ms_total"] / args.steps}
         if frame is not None:
             result["frame_checksum"] = int(frame["rgba"].to(torch.int64).sum().item())
+        result["source_id"] = capi.source_id()
+        if dist_info is not None:
+            dist_info["frame_checksum_matches_single_gpu"] = dist_info.get("frame_checksum_single_gpu") == result.get("frame_checksum")
+            result.update(dist_info)
         if world == 1 and not args.no_extras:
             result.update(extras(args, ds, camc, cfg, step, fence))
         print(json.dumps(result))

@@ -32,7 +32,11 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 1u
+/* Version of this header's struct layouts and entry points.  rr_scene_create refuses a flat scene that names another
+ * version, and rr_abi_version() reports what the loaded library was built with, so a caller compiled against an older
+ * header (round 1: a shorter rr_frame_stats, rr_scene_set_profiling) fails at the first call instead of being written
+ * past its structs.  2: rr_frame_stats grew (level-1 timing, binning, multi-GPU exchange), rr_tuning, rr_abi_version. */
+#define RR_ABI_VERSION 2u
 
 typedef enum rr_status {
     RR_OK = 0,
@@ -50,8 +54,8 @@ typedef enum rr_status {
 
 /* Largest RaytracingConfig::samples accepted.  The reference computes the sub-sample cell size as
  * `(samples + 2).next_power_of_two() / 2` in u16 arithmetic (src/raytracing.rs:297), which overflows from
- * 32767 samples on, and shuffles cell_size^2 cells; 16382 is the last count whose table (16384^2 cells) is
- * still built in reasonable time. */
+ * 32767 samples on, and shuffles cell_size^2 cells; 16382 is the last count of the cell size below that
+ * (cell_size 8192: a table of 8192^2 = 67 M cells, 268 MB of host memory while it is shuffled). */
 #define RR_MAX_SAMPLES 16382u
 /* rr_scene_create: more ENABLED lights than this are refused with RR_ERR_UNSUPPORTED (the shade kernel keeps one bit per
  * enabled light and lane; the reference has no limit, its scenes carry one to three lights). */
@@ -249,6 +253,12 @@ typedef struct rr_frame_stats {
     double ms_binning;      /* device time of that re-ordering (kernel_timing) */
     double ms_trace_closest_level1;          /* the part of ms_trace_closest spent on depth level 1 (the primary rays) */
     uint64_t launches_trace_closest_level1;
+    /* rr_render_multi only (on scenes[0]; zero after any other frame): how the per-device buffers reached scenes[0]'s device */
+    uint32_t multi_devices;       /* handles that took part */
+    uint32_t multi_peer_links;    /* handles whose buffers went device-to-device (peer access enabled both ways, or the same device) */
+    uint32_t multi_staged_links;  /* handles whose buffers were staged through pinned host memory (no peer access between the devices) */
+    uint32_t _pad;
+    double ms_multi_exchange;     /* host wall time from the last device finishing its tiles to the frame being in `out` */
 } rr_frame_stats;
 
 /* Execution knobs of the device path.  None of them changes a single output bit (fixed-point accumulation makes
@@ -267,6 +277,9 @@ typedef struct rr_tuning {
 } rr_tuning;
 
 typedef struct rr_scene rr_scene; /* opaque */
+
+/* RR_ABI_VERSION of the loaded library (never fails). */
+uint32_t rr_abi_version(void);
 
 /* Number of HIP devices visible; 0 if none (never fails). */
 int rr_device_count(void);
@@ -311,9 +324,17 @@ int rr_render(rr_scene* scene, const rr_camera* camera, const rr_config* config,
  * the 32x8-pixel tiles with (tile_index % n_scenes == i) on its device (one host thread per device inside the call),
  * the compact per-device buffers are copied peer-to-peer into scenes[0]'s device, de-interleaved there and copied to
  * `out` (host buffers, as rr_render).  The frame is bit-identical to rr_render's for any n_scenes.  Two handles may sit
- * on the same device (a rehearsal on one GPU); a handle may take part in one call at a time. */
+ * on the same device (a rehearsal on one GPU).  Peer access between scenes[0]'s device and every other device is
+ * checked (hipDeviceCanAccessPeer) and enabled both ways on first use; a pair without it is staged through pinned host
+ * memory instead, and rr_scene_last_stats(scenes[0]) says which way each handle's buffers went.  Every device works on
+ * a non-blocking stream of its own.  Handles are locked in address order: concurrent calls that share handles, in any
+ * order, serialise instead of deadlocking. */
 int rr_render_multi(rr_scene* const* scenes, uint32_t n_scenes, const rr_camera* camera, const rr_config* config,
                     const uint16_t* sample_xy, const rr_frame* out, const volatile int* cancel);
+
+/* Diagnostic: the order in which rr_render_multi locks `scenes` (address order), as indices into the caller's array.
+ * Looks at the pointer values only, never through them (tests/test_abi.py checks the order without a GPU). */
+int rr_multi_lock_order(rr_scene* const* scenes, uint32_t n_scenes, uint32_t* order_out);
 
 /* Progressive form of rr_render.  Stands in for the progressive fill the reference shows while a frame renders:
  * Run::apply_pixels drains the PixelData channel every GUI tick (src/run.rs:506-545) and RendererManager::stop

@@ -12,16 +12,16 @@ import subprocess
 
 import numpy as np
 
-from .flat import (rr_camera, rr_config, rr_flat_scene, rr_frame, rr_frame_stats, rr_material, rr_pick_result, rr_region, rr_tuning)
+from .flat import (RR_ABI_VERSION, rr_camera, rr_config, rr_flat_scene, rr_frame, rr_frame_stats, rr_material, rr_pick_result, rr_region, rr_tuning)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RUSTRAY_HIP_LIB") or os.path.join(_HERE, "librustray_hip.so")  # override: developer A/B builds
 _LIB = None
 
 # every symbol include/rustray_hip.h declares (tests/test_abi.py checks the list against the header)
-EXPORTS = ["rr_device_count", "rr_last_error", "rr_scene_create", "rr_scene_destroy", "rr_scene_update_transforms",
+EXPORTS = ["rr_abi_version", "rr_device_count", "rr_last_error", "rr_scene_create", "rr_scene_destroy", "rr_scene_update_transforms",
            "rr_scene_update_materials", "rr_scene_set_tuning", "rr_scene_get_tuning",
-           "rr_sample_table", "rr_render", "rr_render_multi", "rr_render_progressive", "rr_region_pixel_count", "rr_render_region_device",
+           "rr_sample_table", "rr_render", "rr_render_multi", "rr_multi_lock_order", "rr_render_progressive", "rr_region_pixel_count", "rr_render_region_device",
            "rr_deinterleave_device", "rr_pick", "rr_trace_rays", "rr_scene_last_stats", "rr_post_process", "rr_post_process_device"]
 
 
@@ -32,6 +32,19 @@ class RustrayHipError(RuntimeError):
 
 
 PASS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64)
+
+
+def source_id() -> str:
+    """Identity of the kernel sources next to the library (sha256 over csrc/ + the header, 16 hex digits): what ties a committed
+    counter profile (profiles/*_sq_counters.json) to the build a bench run measures."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(_HERE, "csrc", f) for f in ("rr_api.hip", "rr_kernels.hip", "rr_bvh.cpp", "rr_bvh.h", "rr_device.h", "rr_math.h")]
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "rustray_hip.h"))
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def build(force: bool = False) -> str:
@@ -51,6 +64,12 @@ def lib():
                                "or `make -C rustray_amd/csrc` — there is no fallback path")
         L = C.CDLL(LIB_PATH)
         L.rr_last_error.restype = C.c_char_p
+        got = 1
+        if hasattr(L, "rr_abi_version"):
+            L.rr_abi_version.restype = C.c_uint32
+            got = L.rr_abi_version()
+        if got != RR_ABI_VERSION and not os.environ.get("RUSTRAY_HIP_LIB"):  # (a developer A/B build of an older revision is the caller's business)
+            raise RuntimeError(f"{LIB_PATH} speaks ABI version {got}, this binding {RR_ABI_VERSION}: rebuild the library")
         L.rr_region_pixel_count.restype = C.c_uint64
         L.rr_region_pixel_count.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(rr_region)]
         L.rr_scene_create.argtypes = [C.POINTER(rr_flat_scene), C.c_int, C.POINTER(C.c_void_p)]
@@ -228,7 +247,7 @@ class DeviceScene:
     def stats(self) -> dict:
         st = rr_frame_stats()
         _check(lib().rr_scene_last_stats(self._h, C.byref(st)))
-        return {k: getattr(st, k) for k, _ in rr_frame_stats._fields_}
+        return {k: getattr(st, k) for k, _ in rr_frame_stats._fields_ if not k.startswith("_")}
 
 
 def render_multi(device_scenes, cam: rr_camera, cfg: rr_config, sample_xy=None, aux: bool = True):

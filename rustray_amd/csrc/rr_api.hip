@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -109,6 +110,8 @@ struct rr_scene {
     std::vector<DevBuf> pool_more; // further segments of per-batch counters, for batches with very many launches (kept for the next frame)
     DevBuf tmp_out[4];
     DevBuf multi_part[4], multi_cat[4]; // rr_render_multi: this device's compact buffers; on device slot 0 the concatenation of all
+    hipStream_t multi_stream = nullptr; // rr_render_multi: this handle's own non-blocking stream (created on first use)
+    void* multi_stage[4] = {nullptr, nullptr, nullptr, nullptr}; size_t multi_stage_bytes[4] = {0, 0, 0, 0}; // pinned staging, devices without peer access
     std::vector<uint32_t> h_region_xy;
     rr_region region_cached{0, 0, 0, 0};
     uint32_t region_w = 0, region_h = 0;
@@ -131,6 +134,8 @@ struct rr_scene {
         if (frame_b) (void)hipEventDestroy(frame_b);
         if (count_ready) (void)hipEventDestroy(count_ready);
         if (h_count) (void)hipHostFree(h_count);
+        if (multi_stream) (void)hipStreamDestroy(multi_stream);
+        for (void* p : multi_stage) if (p) (void)hipHostFree(p);
     }
 };
 
@@ -202,7 +207,9 @@ extern "C" int rr_sample_table(uint16_t samples, uint16_t* xy_out, uint32_t* cel
     if (!xy_out && samples) return fail(RR_ERR_INVALID_ARGUMENT, "rr_sample_table: xy_out is NULL");
     if (samples > RR_MAX_SAMPLES) return fail(RR_ERR_UNSUPPORTED, "samples %u > %u", (unsigned)samples, RR_MAX_SAMPLES);
     uint32_t cs = cell_size_of(samples);
-    std::vector<uint32_t> cells((size_t)cs * cs);
+    std::vector<uint32_t> cells;
+    try { cells.resize((size_t)cs * cs); } // 268 MB at the largest cell size: a failure must not cross the C ABI as an exception
+    catch (const std::exception&) { return fail(RR_ERR_OUT_OF_MEMORY, "rr_sample_table: no host memory for %u x %u cells", cs, cs); }
     size_t k = 0;
     for (uint32_t xi = 0; xi < cs; xi++)
         for (uint32_t yi = 0; yi < cs; yi++) cells[k++] = xi | (yi << 16);
@@ -219,6 +226,7 @@ extern "C" int rr_sample_table(uint16_t samples, uint16_t* xy_out, uint32_t* cel
 // ---------------------------------------------------------------------------
 // misc entry points
 // ---------------------------------------------------------------------------
+extern "C" uint32_t rr_abi_version(void) { return RR_ABI_VERSION; }
 extern "C" int rr_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -911,8 +919,11 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     // ---- sample table
     if (!sample_xy) { // the built-in table depends on the sample count only: built once per count, not once per frame
         if (s->table_samples != cfg->samples) {
-            s->table_cache.resize((size_t)cfg->samples * 2);
-            rr_sample_table(cfg->samples, s->table_cache.data(), nullptr);
+            s->table_samples = 0; // the cache names a sample count only once its table is complete
+            try { s->table_cache.resize((size_t)cfg->samples * 2); }
+            catch (const std::exception&) { return fail(RR_ERR_OUT_OF_MEMORY, "no host memory for the sub-sample table"); }
+            const int rct = rr_sample_table(cfg->samples, s->table_cache.data(), nullptr);
+            if (rct != RR_OK) return rct;
             s->table_samples = cfg->samples;
         }
         sample_xy = s->table_cache.data();
@@ -1018,7 +1029,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
 
     uint32_t* pool = s->pool.as<uint32_t>();
     unsigned long long* counters = s->counters.as<unsigned long long>();
-    const int trace_grid = s->n_cus * RR_TRACE_WAVES; // RR_STACK_DEPTH KB of LDS stack per 256-thread workgroup
+    const int trace_grid = s->n_cus * RR_CLOSEST_WAVES, shadow_grid = s->n_cus * RR_SHADOW_WAVES; // RR_STACK_DEPTH KB of LDS stack per 256-thread workgroup
     const int shade_grid_max = s->n_cus * 2 * RR_SHADE_WAVES;
     const uint32_t L = s->n_enabled_lights;
 
@@ -1107,11 +1118,11 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
                     ScopedTimer t(s, st, 1);
                     if (sq_fixed) {
                         const uint32_t sq_packets = (sq_chunk_cap / RR_WAVE) * L;
-                        const int sgrid = (int)std::min<uint64_t>(((uint64_t)sq_packets * RR_WAVE + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)trace_grid);
+                        const int sgrid = (int)std::min<uint64_t>(((uint64_t)sq_packets * RR_WAVE + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)shadow_grid);
                         hipLaunchKernelGGL(k_trace_shadow<true>, dim3(sgrid), dim3(RR_BLOCK), 0, st, s->view, SQ, sq_counts, segcap, sq_valid, sq_packets, shead, acc);
                     } else {
                         const uint64_t sq_ub = (c1 - c0) * L;
-                        const int sgrid = (int)std::min<uint64_t>((sq_ub + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)trace_grid);
+                        const int sgrid = (int)std::min<uint64_t>((sq_ub + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)shadow_grid);
                         hipLaunchKernelGGL(k_trace_shadow<false>, dim3(sgrid), dim3(RR_BLOCK), 0, st, s->view, SQ, sq_counts, segcap, sq_valid, 0u, shead, acc);
                     }
                 }
@@ -1306,11 +1317,57 @@ extern "C" int rr_deinterleave_device(uint32_t width, uint32_t height, uint32_t 
     return RR_OK;
 }
 
+// Lock order of a set of scene handles: by address (std::less is a total order on pointers).
+static std::vector<rr_scene*> multi_lock_order(rr_scene* const* scenes, uint32_t n) {
+    std::vector<rr_scene*> v(scenes, scenes + n);
+    std::sort(v.begin(), v.end(), std::less<rr_scene*>());
+    return v;
+}
+// test hook (tests/test_abi.py): the order in which rr_render_multi would lock `scenes`, as indices into the caller's array
+extern "C" int rr_multi_lock_order(rr_scene* const* scenes, uint32_t n_scenes, uint32_t* order_out) {
+    if (!scenes || !order_out || n_scenes == 0) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
+    const std::vector<rr_scene*> v = multi_lock_order(scenes, n_scenes);
+    for (uint32_t k = 0; k < n_scenes; k++)
+        for (uint32_t i = 0; i < n_scenes; i++) if (scenes[i] == v[k]) { order_out[k] = i; break; }
+    return RR_OK;
+}
+
+// Peer access between two devices, both ways: checked once per ordered pair, enabled on first use.
+// false = no direct path (the caller stages through the host).  The same device counts as direct.
+static std::mutex g_peer_mu;
+static std::map<std::pair<int, int>, bool> g_peer_state; // (from, to) -> `from` may access memory of `to`
+static bool enable_peer_one_way(int from, int to) {
+    auto it = g_peer_state.find({from, to});
+    if (it != g_peer_state.end()) return it->second;
+    bool ok = false;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, from, to) == hipSuccess && can) {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (hipSetDevice(from) == hipSuccess) {
+            const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+            ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+            (void)hipGetLastError(); // "already enabled" is not an error of this call
+        }
+        (void)hipSetDevice(cur);
+    }
+    g_peer_state[{from, to}] = ok;
+    return ok;
+}
+static bool ensure_peer_access(int a, int b) {
+    if (a == b) return true;
+    std::lock_guard<std::mutex> lk(g_peer_mu);
+    const bool ab = enable_peer_one_way(a, b), ba = enable_peer_one_way(b, a);
+    return ab && ba;
+}
+
 // ---------------------------------------------------------------------------
 // one frame on several GPUs from ONE host process (the reference host is one process, src/renderer.rs:105-172):
 // one host thread per device renders that device's interleaved tiles, the compact per-device buffers are copied
 // peer-to-peer (xGMI) into device 0, de-interleaved there and copied to the host once.  No collective library is
-// involved: the exchange is n - 1 point-to-point copies of 1 / n of the frame each.
+// involved: the exchange is n - 1 point-to-point copies of 1 / n of the frame each.  Every device works on its own
+// non-blocking stream.  UNVERIFIED ON N > 1 DEVICES until an N-GPU node has run it (the pool hands out 1-GPU boxes;
+// tests/test_gpu_multi.py puts several handles on device 0).
 // ---------------------------------------------------------------------------
 extern "C" int rr_render_multi(rr_scene* const* scenes, uint32_t n_scenes, const rr_camera* cam, const rr_config* cfg,
                                const uint16_t* sample_xy, const rr_frame* out, const volatile int* cancel) {
@@ -1335,19 +1392,36 @@ extern "C" int rr_render_multi(rr_scene* const* scenes, uint32_t n_scenes, const
         offset[i] = total; total += count[i];
     }
     rr_scene* s0 = scenes[0];
+    // Handles are locked in ADDRESS order, whatever order the caller passed them in: two calls that share handles in
+    // opposite orders (or a call racing rr_render on one of them) then serialise instead of deadlocking.
     std::vector<std::unique_lock<std::mutex>> locks;
-    for (uint32_t i = 0; i < n_scenes; i++) locks.emplace_back(scenes[i]->mu); // address order is the caller's: a handle is in one multi call at a time
+    for (rr_scene* s : multi_lock_order(scenes, n_scenes)) locks.emplace_back(s->mu);
+    // Peer access between device 0 and every other device taking part: checked, and enabled both ways on first use.
+    // A pair without it does not fall back silently to whatever hipMemcpyPeerAsync does: its buffers are staged
+    // through pinned host memory here, and the frame's stats say so.
+    std::vector<char> direct(n_scenes, 1);
+    uint32_t n_peer = 0, n_staged = 0;
+    for (uint32_t i = 1; i < n_scenes; i++) {
+        direct[i] = ensure_peer_access(scenes[i]->device, s0->device) ? 1 : 0;
+        if (direct[i]) n_peer++; else n_staged++;
+    }
+    auto own_stream = [](rr_scene* s) -> int { // on the scene's device
+        if (!s->multi_stream) HIP_TRY(hipStreamCreateWithFlags(&s->multi_stream, hipStreamNonBlocking));
+        return RR_OK;
+    };
     // device 0: the concatenation of the compact buffers (rank order) and the frame-order buffers
     HIP_TRY(hipSetDevice(s0->device));
+    { int rc = own_stream(s0); if (rc != RR_OK) return rc; }
     for (int k = 0; k < 4; k++)
         if (host[k]) { HIP_TRY(s0->multi_cat[k].reserve(np * esz[k])); HIP_TRY(s0->tmp_out[k].reserve(np * esz[k])); }
-    // every device renders its tiles into its own compact buffers, then pushes them into device 0's concatenation
+    // every device renders its tiles into its own compact buffers on its own stream, then pushes them towards device 0
     std::vector<int> rcs(n_scenes, RR_OK);
     std::vector<std::string> errs(n_scenes);
     auto work = [&](uint32_t i) {
         rr_scene* s = scenes[i];
         auto body = [&]() -> int {
             HIP_TRY(hipSetDevice(s->device));
+            { int rc = own_stream(s); if (rc != RR_OK) return rc; }
             rr_frame dev{};
             void** devp[4] = {(void**)&dev.rgba8, (void**)&dev.normal, (void**)&dev.depth, (void**)&dev.object_id};
             for (int k = 0; k < 4; k++) {
@@ -1356,13 +1430,25 @@ extern "C" int rr_render_multi(rr_scene* const* scenes, uint32_t n_scenes, const
                 else { HIP_TRY(s->multi_part[k].reserve(std::max<uint64_t>(count[i], 1) * esz[k])); *devp[k] = s->multi_part[k].p; }
             }
             rr_region rg{TW, TH, n_scenes, i};
-            int rc = render_region_locked(s, cam, cfg, sample_xy, &rg, &dev, false, nullptr, cancel);
+            int rc = render_region_locked(s, cam, cfg, sample_xy, &rg, &dev, false, s->multi_stream, cancel);
             if (rc != RR_OK) return rc;
             if (i != 0)
-                for (int k = 0; k < 4; k++)
-                    if (host[k] && count[i])
-                        HIP_TRY(hipMemcpyPeerAsync((char*)s0->multi_cat[k].p + offset[i] * esz[k], s0->device, s->multi_part[k].p, s->device, count[i] * esz[k], nullptr));
-            HIP_TRY(hipStreamSynchronize(nullptr));
+                for (int k = 0; k < 4; k++) {
+                    if (!host[k] || !count[i]) continue;
+                    const size_t bytes = count[i] * esz[k];
+                    void* dst = (char*)s0->multi_cat[k].p + offset[i] * esz[k];
+                    if (s->device == s0->device) HIP_TRY(hipMemcpyAsync(dst, s->multi_part[k].p, bytes, hipMemcpyDeviceToDevice, s->multi_stream));
+                    else if (direct[i]) HIP_TRY(hipMemcpyPeerAsync(dst, s0->device, s->multi_part[k].p, s->device, bytes, s->multi_stream));
+                    else { // no peer access: device -> pinned host here, host -> device 0 after the join
+                        if (s->multi_stage_bytes[k] < bytes) {
+                            if (s->multi_stage[k]) { (void)hipHostFree(s->multi_stage[k]); s->multi_stage[k] = nullptr; s->multi_stage_bytes[k] = 0; }
+                            HIP_TRY(hipHostMalloc(&s->multi_stage[k], bytes, hipHostMallocPortable));
+                            s->multi_stage_bytes[k] = bytes;
+                        }
+                        HIP_TRY(hipMemcpyAsync(s->multi_stage[k], s->multi_part[k].p, bytes, hipMemcpyDeviceToHost, s->multi_stream));
+                    }
+                }
+            HIP_TRY(hipStreamSynchronize(s->multi_stream));
             return RR_OK;
         };
         rcs[i] = body();
@@ -1372,17 +1458,26 @@ extern "C" int rr_render_multi(rr_scene* const* scenes, uint32_t n_scenes, const
     for (uint32_t i = 1; i < n_scenes; i++) threads.emplace_back(work, i);
     work(0);
     for (auto& t : threads) t.join();
+    const auto t_joined = std::chrono::steady_clock::now();
     for (uint32_t i = 0; i < n_scenes; i++)
         if (rcs[i] != RR_OK) return fail(rcs[i], "device slot %u: %s", i, errs[i].c_str());
     HIP_TRY(hipSetDevice(s0->device));
+    for (uint32_t i = 1; i < n_scenes; i++) {
+        if (direct[i]) continue;
+        for (int k = 0; k < 4; k++)
+            if (host[k] && count[i])
+                HIP_TRY(hipMemcpyAsync((char*)s0->multi_cat[k].p + offset[i] * esz[k], scenes[i]->multi_stage[k], count[i] * esz[k], hipMemcpyHostToDevice, s0->multi_stream));
+    }
     for (int k = 0; k < 4; k++) {
         if (!host[k]) continue;
-        int rc = rr_deinterleave_device(W, H, TW, TH, n_scenes, (uint32_t)esz[k], s0->multi_cat[k].p, s0->tmp_out[k].p, s0->device, nullptr);
+        int rc = rr_deinterleave_device(W, H, TW, TH, n_scenes, (uint32_t)esz[k], s0->multi_cat[k].p, s0->tmp_out[k].p, s0->device, s0->multi_stream);
         if (rc != RR_OK) return rc;
     }
-    HIP_TRY(hipStreamSynchronize(nullptr));
     for (int k = 0; k < 4; k++)
-        if (host[k]) HIP_TRY(hipMemcpy(host[k], s0->tmp_out[k].p, np * esz[k], hipMemcpyDeviceToHost));
+        if (host[k]) HIP_TRY(hipMemcpyAsync(host[k], s0->tmp_out[k].p, np * esz[k], hipMemcpyDeviceToHost, s0->multi_stream));
+    HIP_TRY(hipStreamSynchronize(s0->multi_stream));
+    s0->stats.multi_devices = n_scenes; s0->stats.multi_peer_links = n_peer; s0->stats.multi_staged_links = n_staged;
+    s0->stats.ms_multi_exchange = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_joined).count();
     return RR_OK;
 }
 
@@ -1509,7 +1604,7 @@ extern "C" int rr_trace_rays(rr_scene* s, const float* origins, const float* dir
     DFrame fr;
     memset(&fr, 0, sizeof fr);
     DPrimary pr{nullptr, 0ull, 0u, 1u};
-    const int grid = (int)std::min<uint64_t>(((uint64_t)n + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)s->n_cus * RR_TRACE_WAVES);
+    const int grid = (int)std::min<uint64_t>(((uint64_t)n + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)s->n_cus * RR_CLOSEST_WAVES);
     hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(RR_BLOCK), 0, nullptr, s->view, q, bc.as<uint32_t>(), bc.as<uint32_t>() + 1,
                        (const DShadeConst*)nullptr, (const uint32_t*)nullptr, pr, (unsigned long long*)nullptr);
     HIP_TRY(hipGetLastError());

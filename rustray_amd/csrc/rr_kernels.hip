@@ -30,6 +30,12 @@
 #ifndef RR_TRACE_WAVES
 #define RR_TRACE_WAVES 4 // waves per SIMD the trace kernels are built for (bounds VGPRs; LDS stack: RR_STACK_DEPTH KB per workgroup)
 #endif
+#ifndef RR_CLOSEST_WAVES
+#define RR_CLOSEST_WAVES RR_TRACE_WAVES
+#endif
+#ifndef RR_SHADOW_WAVES
+#define RR_SHADOW_WAVES RR_TRACE_WAVES
+#endif
 #define RR_WAVE 64
 #ifndef RR_DYN_FETCH
 #define RR_DYN_FETCH 4
@@ -1227,11 +1233,10 @@ struct DShadeConst { DSceneView sc; DFrame fr; };
 // PRIMARY: depth level 1.  The rays are derived from their index (primary_ray), only the 16-B hit record is written;
 // block 0 publishes the level's size for the shade kernel and counts the rays.
 template <bool PRIMARY>
-__global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_closest(DSceneView sc, DRayQueue q, uint32_t* __restrict__ q_count,
+__global__ __launch_bounds__(RR_BLOCK, RR_CLOSEST_WAVES) void k_trace_closest(DSceneView sc, DRayQueue q, uint32_t* __restrict__ q_count,
                                                             uint32_t* head, const DShadeConst* __restrict__ kc, const uint32_t* __restrict__ slot_xy, DPrimary pr,
                                                             unsigned long long* counters) {
     __shared__ int s_stack[RR_STACK_DEPTH * RR_BLOCK];
-    const DFrame& fr = kc->fr; // read once per packet (primary_ray): not worth 49 SGPRs across the walks
     RR_UTIL_KIND(PRIMARY ? 0u : 1u)
     uint32_t n;
     if (PRIMARY) {
@@ -1276,8 +1281,9 @@ __global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_closest(DSce
         const uint32_t i = pkt * RR_WAVE + lane;
         const uint32_t ii = min(i, n - 1u); // the lanes past the end of the last packet repeat its last ray, so that the packet form below runs with all lanes
         f3 ro, rd; uint32_t depth;
-        if (PRIMARY) { uint32_t pix_, smp_; primary_ray(fr, slot_xy, pr, ii, &ro, &rd, &pix_, &smp_); depth = 1u; }
-        else {
+        if constexpr (PRIMARY) { // the frame constants are read once per packet (not worth 49 SGPRs across the walks); kc is NULL in the <false> build's launches
+            uint32_t pix_, smp_; primary_ray(kc->fr, slot_xy, pr, ii, &ro, &rd, &pix_, &smp_); depth = 1u;
+        } else {
             const float4 r0 = q.r0[ii], r1 = q.r1[ii];
             ro = mk3(r0.x, r0.y, r0.z); rd = mk3(r1.x, r1.y, r1.z);
             depth = (q.r2[ii].x >> 16) & 0xffu;
@@ -1675,7 +1681,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
 // light), slots p * 64 .. p * 64 + 63, lanes by sq_valid[p]; n_packets given.  Otherwise the dense sharded queue of the
 // deeper levels (k_shade), n_packets from the shard counts.
 template <bool FIXED>
-__global__ __launch_bounds__(RR_BLOCK, RR_TRACE_WAVES) void k_trace_shadow(DSceneView sc, DShadowQueue sq, const uint32_t* __restrict__ sq_counts, uint32_t sq_segcap,
+__global__ __launch_bounds__(RR_BLOCK, RR_SHADOW_WAVES) void k_trace_shadow(DSceneView sc, DShadowQueue sq, const uint32_t* __restrict__ sq_counts, uint32_t sq_segcap,
                                                            const unsigned long long* __restrict__ sq_valid, uint32_t n_fixed_packets,
                                                            uint32_t* head, DAccum acc) {
     __shared__ int s_stack[RR_STACK_DEPTH * RR_BLOCK];

@@ -244,43 +244,82 @@ class TiledFrame:
             self._index = torch.from_numpy(idx).to(device)
         return self._index
 
+    # bytes per pixel of the buffers a rank can render, in packing order
+    _SPEC = (("rgba", "uint8", 4, 4), ("normal", "float32", 3, 12), ("depth", "float32", 1, 4), ("object_id", "int32", 1, 4))
+
+    def alloc(self, device, aux: bool, via_cpu: bool = False) -> dict:
+        """Persistent buffers of this rank, allocated ONCE (outside any timed region) and reused every frame:
+        `pack` = one byte buffer with a section of max_count pixels per rendered buffer (every section starts 4-byte
+        aligned on every rank); the returned compact views into it are what `rr_render_region_device` fills, so the
+        gather sends the pack as it is.  Rank 0 also holds the gather target (world x pack), the rank-ordered
+        concatenation per buffer and the frame-order outputs."""
+        import torch
+        key = (str(device), bool(aux), bool(via_cpu))
+        if getattr(self, "_alloc_key", None) == key:
+            return self._parts
+        spec = [sp for sp in self._SPEC if aux or sp[0] == "rgba"]
+        pack_bytes = self.max_count * sum(sp[3] for sp in spec)
+        self._pack = torch.zeros(max(pack_bytes, 4), dtype=torch.uint8, device=device)
+        self._parts, self._section, off = {}, {}, 0
+        n = self.n_pixels()
+        for name, dt, comps, width in spec:
+            self._section[name] = (off, width, getattr(torch, dt), comps)
+            view = self._pack[off: off + n * width].view(getattr(torch, dt))
+            self._parts[name] = view.reshape(n, comps) if comps > 1 else view.reshape(n)
+            off += self.max_count * width
+        total = sum(self.counts)
+        self._pack_cpu = torch.zeros_like(self._pack, device="cpu").pin_memory() if (via_cpu and torch.cuda.is_available()) else (torch.zeros_like(self._pack, device="cpu") if via_cpu else None)
+        self._gbuf = self._cat = self._frame = None
+        if self.world_size > 1 and self.rank == 0:
+            self._gbuf = torch.zeros((self.world_size, max(pack_bytes, 4)), dtype=torch.uint8, device="cpu" if via_cpu else device)
+            self._cat = {name: torch.zeros(total * width, dtype=torch.uint8, device=device) for name, _, _, width in spec}
+        if self.rank == 0:
+            self._frame = {name: torch.zeros((self.height * self.width, comps), dtype=getattr(torch, dt), device=device) for name, dt, comps, _ in spec}
+        self._alloc_key = key
+        return self._parts
+
     def gather(self, parts: dict, use_device_kernel: bool = False, via_cpu: bool = False) -> Optional[dict]:
-        """ONE collective per frame: every rank packs its compact buffers (RGBA8 and whichever aux buffers were rendered)
-        into one byte buffer, rank 0 gathers them (backend "nccl" = RCCL over xGMI, device tensors; `via_cpu` stages
-        through host memory for "gloo", which cannot gather device tensors) and de-interleaves each buffer into frame order."""
+        """ONE collective per frame: every rank sends its pack (RGBA8 and whichever aux buffers were rendered, one byte
+        buffer), rank 0 gathers them (backend "nccl" = RCCL over xGMI, device tensors; `via_cpu` stages through host
+        memory for "gloo", which cannot gather device tensors) and de-interleaves each buffer into frame order.
+        With `parts` from `alloc()` nothing is allocated or packed here: the views ARE the pack's sections."""
         import torch
         import torch.distributed as dist
         keys = list(parts.keys())
-        flat = {k: parts[k].reshape(self.n_pixels(), -1) for k in keys}
+        persistent = getattr(self, "_alloc_key", None) is not None and all(parts[k] is self._parts.get(k) for k in keys)
+        if not persistent:   # ad-hoc tensors (tests, one-off frames): pack them into freshly allocated buffers
+            dev = parts[keys[0]].device
+            self.alloc(dev, aux=len(keys) > 1, via_cpu=via_cpu)
+            for k in keys:
+                self._parts[k].copy_(parts[k].reshape(self._parts[k].shape))
+        dev = self._pack.device
         gathered = None
         if self.world_size > 1:
-            dev = flat[keys[0]].device
-            width = {k: flat[k].shape[1] * flat[k].element_size() for k in keys}        # bytes per pixel of each buffer
-            pack = torch.zeros(self.max_count * sum(width.values()), dtype=torch.uint8, device=dev)
-            off = 0
-            for k in keys:   # sections of max_count pixels each, so that every section starts 4-byte aligned on every rank
-                n = self.n_pixels() * width[k]
-                pack[off: off + n] = flat[k].contiguous().view(torch.uint8).reshape(-1)
-                off += self.max_count * width[k]
+            send = self._pack
             if via_cpu:
-                pack = pack.cpu()
-            gl = [torch.empty_like(pack) for _ in range(self.world_size)] if self.rank == 0 else None
-            dist.gather(pack, gl, dst=0)
+                self._pack_cpu.copy_(self._pack)
+                send = self._pack_cpu
+            gl = list(self._gbuf.unbind(0)) if self.rank == 0 else None
+            dist.gather(send, gl, dst=0)
             if self.rank != 0:
                 return None
-            gathered, off = {}, 0
+            gathered = {}
             for k in keys:
-                rows = [gl[r][off: off + self.counts[r] * width[k]] for r in range(self.world_size)]
-                gathered[k] = torch.cat(rows).to(dev).view(flat[k].dtype).reshape(-1, flat[k].shape[1])
-                off += self.max_count * width[k]
+                off, width, dt, comps = self._section[k]
+                rows = [self._gbuf[r, off: off + self.counts[r] * width] for r in range(self.world_size)]
+                if via_cpu:
+                    self._cat[k].copy_(torch.cat(rows))
+                else:
+                    torch.cat(rows, out=self._cat[k])
+                gathered[k] = self._cat[k].view(dt).reshape(-1, comps)
         out = {}
         for k in keys:
-            cat = gathered[k] if gathered is not None else flat[k]
+            off, width, dt, comps = self._section[k]
+            cat = gathered[k] if gathered is not None else self._parts[k].reshape(self.n_pixels(), comps)
             if use_device_kernel and cat.is_cuda:
-                frame = torch.empty((self.height * self.width, cat.shape[1]), dtype=cat.dtype, device=cat.device)
-                cat = cat.contiguous()
+                frame = self._frame[k]
                 capi.deinterleave_device(self.width, self.height, self.tile_w, self.tile_h, self.world_size,
-                                         cat.shape[1] * cat.element_size(), cat.data_ptr(), frame.data_ptr(),
+                                         width, cat.data_ptr(), frame.data_ptr(),
                                          cat.device.index or 0, torch.cuda.current_stream().cuda_stream)
             else:
                 frame = cat.index_select(0, self._frame_index(cat.device))
@@ -288,17 +327,14 @@ class TiledFrame:
         return out
 
 
-def render_region_torch(device_scene: capi.DeviceScene, cam, cfg, tf: TiledFrame, aux: bool = False, sample_xy=None) -> dict:
-    """Render this rank's tiles into fresh torch CUDA tensors on torch's current stream."""
+def render_region_torch(device_scene: capi.DeviceScene, cam, cfg, tf: TiledFrame, aux: bool = False, sample_xy=None, via_cpu: bool = False) -> dict:
+    """Render this rank's tiles on torch's current stream, straight into the sections of the rank's persistent pack
+    buffer (TiledFrame.alloc): nothing is allocated per frame and `tf.gather` sends the pack as it is."""
     import torch
-    n = tf.n_pixels()
     dev = torch.device("cuda", device_scene.device)
-    parts = {"rgba": torch.empty((n, 4), dtype=torch.uint8, device=dev)}
+    parts = tf.alloc(dev, aux, via_cpu=via_cpu)
     ptrs = [parts["rgba"].data_ptr(), None, None, None]
     if aux:
-        parts["normal"] = torch.empty((n, 3), dtype=torch.float32, device=dev)
-        parts["depth"] = torch.empty((n,), dtype=torch.float32, device=dev)
-        parts["object_id"] = torch.empty((n,), dtype=torch.int32, device=dev)
         ptrs = [parts["rgba"].data_ptr(), parts["normal"].data_ptr(), parts["depth"].data_ptr(), parts["object_id"].data_ptr()]
     device_scene.render_region_device(cam, cfg, tf.region(), ptrs, torch.cuda.current_stream(dev).cuda_stream, sample_xy)
     return parts

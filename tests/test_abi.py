@@ -27,6 +27,35 @@ def test_every_declared_symbol_is_exported():
     assert set(capi.EXPORTS) <= set(names)
 
 
+def test_abi_version_is_reported_and_checked():
+    """rr_frame_stats grew without a size field.  The layouts are versioned instead: the header's RR_ABI_VERSION,
+    the library's rr_abi_version() and the binding's constant agree, and a flat scene that names another version is refused
+    before anything is written through a caller's pointers."""
+    from rustray_amd import flat
+    src = open(os.path.join(ROOT, "include", "rustray_hip.h")).read()
+    header_version = int(re.search(r"#define RR_ABI_VERSION (\d+)u", src).group(1))
+    L = capi.lib()
+    L.rr_abi_version.restype = C.c_uint32
+    assert header_version == flat.RR_ABI_VERSION == L.rr_abi_version() == 2
+    # rr_frame_stats as the header lists it: 17 8-byte fields of round 2 + 4 u32 + 1 double of the multi-GPU exchange
+    assert C.sizeof(flat.rr_frame_stats) == 17 * 8 + 4 * 4 + 8
+
+
+def test_render_multi_locks_handles_in_address_order():
+    """Two rr_render_multi calls that share handles in opposite orders must take the handle mutexes in ONE order
+    (ADVICE r2 / VERDICT r2 item 4).  rr_multi_lock_order reports that order from the pointer values alone."""
+    L = capi.lib()
+    L.rr_multi_lock_order.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+    fake = [0x7000, 0x1000, 0x9000, 0x3000]   # never dereferenced
+    for perm in ([0, 1, 2, 3], [3, 2, 1, 0], [2, 0, 3, 1]):
+        handles = (C.c_void_p * 4)(*[fake[i] for i in perm])
+        order = (C.c_uint32 * 4)()
+        assert L.rr_multi_lock_order(handles, 4, order) == 0
+        locked = [handles[i] for i in order]
+        assert locked == sorted(fake), (perm, list(order))
+    assert L.rr_multi_lock_order(None, 0, None) == -1
+
+
 def test_struct_sizes_match_header():
     # sizes implied by the header's field lists (natural alignment)
     from rustray_amd import flat

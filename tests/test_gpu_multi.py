@@ -43,3 +43,41 @@ def test_multi_rejects_bad_arguments(hip):
             hip.render_multi([ds, ds], cam, cfg)        # the same handle twice
         with pytest.raises(hip.RustrayHipError):
             hip.render_multi([], cam, cfg)
+
+
+def test_multi_reports_how_the_buffers_travelled_and_concurrent_callers_do_not_deadlock(hip):
+    """rr_scene_last_stats(scenes[0]) after rr_render_multi: handles, direct (peer / same device) and host-staged links.
+    Two threads calling with the SAME handles in opposite orders serialise (address-ordered locks) and both get the frame."""
+    import threading
+    fs = load_scene("spheres")
+    cam = camera_for(fs, 96, 64).c_struct()
+    cfg = make_config(samples=2, monte_carlo=True, seed=3)
+    scenes = [hip.DeviceScene(fs, 0) for _ in range(3)]
+    try:
+        ref = scenes[0].render(cam, cfg)
+        hip.render_multi(scenes, cam, cfg)
+        st = scenes[0].stats()
+        assert st["multi_devices"] == 3 and st["multi_peer_links"] == 2 and st["multi_staged_links"] == 0
+        assert st["ms_multi_exchange"] > 0.0
+        scenes[0].render(cam, cfg)
+        assert scenes[0].stats()["multi_devices"] == 0   # a single-handle frame resets it
+        results, errors = {}, []
+
+        def run(tag, order):
+            try:
+                for _ in range(4):
+                    results[tag] = hip.render_multi(order, cam, cfg)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+        ts = [threading.Thread(target=run, args=("fwd", scenes)), threading.Thread(target=run, args=("rev", scenes[::-1]))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in ts), "rr_render_multi deadlocked on handles passed in opposite orders"
+        assert not errors, errors
+        _same(results["fwd"], ref)
+        _same(results["rev"], ref)
+    finally:
+        for s in scenes:
+            s.close()

@@ -2,8 +2,8 @@
 # Developer profile: per-kernel time of one scene, level 1 (k_*<true>) against the deeper levels (k_*<false>), from rocprofv3 --kernel-trace --stats.
 # usage (through gpurun): tools/level_split.sh <tag> <bench args>
 tag=$1; shift
-R=$GRAFT_REPO_ROOT
-out=$R/gpurun_out/$tag
+R=${RR_CODE_ROOT:-$GRAFT_REPO_ROOT}   # the code (a frozen copy under tools/gpu.sh); output always goes to the real gpurun_out/
+out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 "$@" > $out/bench.json 2> $out/err.txt || { echo failed; tail -n 3 $out/err.txt; exit 1; }

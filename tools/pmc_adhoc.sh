@@ -1,8 +1,8 @@
 #!/bin/bash
 # Developer tool: one extra PMC pass over one bench frame.  usage (through gpurun): tools/pmc_adhoc.sh <name> COUNTER...  -> gpurun_out/adhoc/<name>.txt
 name=$1; shift
-R=$GRAFT_REPO_ROOT
-out=$R/gpurun_out/adhoc; mkdir -p $out
+R=${RR_CODE_ROOT:-$GRAFT_REPO_ROOT}   # the code (a frozen copy under tools/gpu.sh); output always goes to the real gpurun_out/
+out=$GRAFT_REPO_ROOT/gpurun_out/adhoc; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_$name
 timeout -k 10 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$name -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 0 > $out/$name.json 2> $out/$name.err || { echo "pass $name failed"; tail -n 3 $out/$name.err; exit 1; }

@@ -5,8 +5,8 @@
 #        python tools/summarize_profiles.py <tag> <name>           -> profiles/<name>_*.{json,csv}
 # "quick": SQ + kernel stats only (before / after comparisons of one kernel change).
 tag=$1; mode=$2
-R=$GRAFT_REPO_ROOT
-out=$R/gpurun_out/$tag
+R=${RR_CODE_ROOT:-$GRAFT_REPO_ROOT}   # the code (a frozen copy under tools/gpu.sh); output always goes to the real gpurun_out/
+out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-extras"
