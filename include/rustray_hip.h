@@ -304,6 +304,14 @@ int rr_scene_update_transforms(rr_scene* scene, const float* trans, const float*
  * texture uploaded at creation.  Meshes, acceleration structures and texture images are not touched. */
 int rr_scene_update_materials(rr_scene* scene, const rr_material* materials, uint32_t n_materials);
 
+/* Compatibility switches: behaviours of EARLIER reference binaries that the source at HEAD no longer has.  Default 0 = HEAD.
+ * RR_COMPAT_OCCLUDER_ALPHA_SHADOWS: a shadow is attenuated by the OCCLUDER's material.alpha, where HEAD takes the
+ * receiver's (`shadow_source_alpha = material.alpha`, src/raytracing.rs:898).  That is what the binary behind the 2022-05
+ * README renderings did (tests/test_ref_shots.py: with it the product matches those renderings over the whole frame);
+ * it exists so that the shipped kernels can be checked against the only outputs the reference holds. */
+#define RR_COMPAT_OCCLUDER_ALPHA_SHADOWS 1u
+int rr_scene_set_compat(rr_scene* scene, uint32_t flags);
+
 /* Execution knobs (see rr_tuning). */
 int rr_scene_set_tuning(rr_scene* scene, const rr_tuning* tuning);
 int rr_scene_get_tuning(const rr_scene* scene, rr_tuning* tuning);

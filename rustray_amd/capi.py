@@ -20,7 +20,7 @@ _LIB = None
 
 # every symbol include/rustray_hip.h declares (tests/test_abi.py checks the list against the header)
 EXPORTS = ["rr_abi_version", "rr_device_count", "rr_last_error", "rr_scene_create", "rr_scene_destroy", "rr_scene_update_transforms",
-           "rr_scene_update_materials", "rr_scene_set_tuning", "rr_scene_get_tuning",
+           "rr_scene_update_materials", "rr_scene_set_tuning", "rr_scene_get_tuning", "rr_scene_set_compat",
            "rr_sample_table", "rr_render", "rr_render_multi", "rr_multi_lock_order", "rr_render_progressive", "rr_region_pixel_count", "rr_render_region_device",
            "rr_deinterleave_device", "rr_pick", "rr_trace_rays", "rr_scene_last_stats", "rr_post_process", "rr_post_process_device"]
 
@@ -243,6 +243,11 @@ class DeviceScene:
 
     def set_profiling(self, on: bool):
         self.set_tuning(kernel_timing=1 if on else 0)
+
+    def set_compat(self, flags: int):
+        """rr_scene_set_compat: behaviours of earlier reference binaries (1 = shadows attenuated by the occluder's alpha)."""
+        lib().rr_scene_set_compat.argtypes = [C.c_void_p, C.c_uint32]
+        _check(lib().rr_scene_set_compat(self._h, C.c_uint32(flags)))
 
     def stats(self) -> dict:
         st = rr_frame_stats()

@@ -1260,6 +1260,14 @@ extern "C" int rr_scene_last_stats(const rr_scene* cs, rr_frame_stats* out) {
     return RR_OK;
 }
 
+extern "C" int rr_scene_set_compat(rr_scene* s, uint32_t flags) {
+    if (!s) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (flags & ~RR_COMPAT_OCCLUDER_ALPHA_SHADOWS) return fail(RR_ERR_INVALID_ARGUMENT, "unknown compatibility flags 0x%x", flags);
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->view.compat = flags; // the scene view is passed to the kernels by value with every launch
+    return RR_OK;
+}
+
 extern "C" int rr_scene_set_tuning(rr_scene* s, const rr_tuning* t) {
     if (!s || !t) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
     if (t->struct_size != sizeof(rr_tuning)) return fail(RR_ERR_INVALID_ARGUMENT, "rr_tuning::struct_size %u, library expects %zu", t->struct_size, sizeof(rr_tuning));

@@ -122,6 +122,7 @@ struct DSceneView {
     const float4* item_boxes; // the same padded world boxes per item: [2 i] = lo, [2 i + 1] = hi (the packet form of the top level, trace_closest_packet)
     uint32_t any_alpha_occluder; // some item's material has an alpha map: its shadow attenuation can be NaN (k_shade, want_shadow)
     uint32_t general_w;      // some trans_inv has a w row other than (0,0,0,1)
+    uint32_t compat;         // RR_COMPAT_* (rr_scene_set_compat): behaviours of earlier reference binaries; 0 = the source at HEAD
 };
 
 // ---- per-frame constants ----------------------------------------------------------------

@@ -1756,8 +1756,9 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADOW_WAVES) void k_trace_shadow(DSce
             const bool occluded = sel.found && sel.within;
             float factor = 1.0f;
             if (occluded) {
-                float shadow_source_alpha = rr_global(sc.materials)[rr_global(sc.items)[rcv_item].material].alpha; // the RECEIVER's material.alpha (:898)
                 const DItem& occ = rr_global(sc.items)[sel.item];
+                // the RECEIVER's material.alpha (:898); the 2022-05 binary took the occluder's (RR_COMPAT_OCCLUDER_ALPHA_SHADOWS, wave-uniform)
+                float shadow_source_alpha = rr_global(sc.materials)[(sc.compat & 1u) ? occ.material : rr_global(sc.items)[rcv_item].material].alpha;
                 if (occ.flags & RR_IF_OCCLUDER_ALPHA_TEX) {
                     // the reference evaluates the RECEIVER's get_uv with the occluder's face id (:905)
                     const DItem& rcv = rr_global(sc.items)[rcv_item];
