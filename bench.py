@@ -57,19 +57,48 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # 1024 SIMD-32 x 2.4 GHz / 2 issue cycles per wave64 VALU instruction = 1228.8 G wave-inst/s
 
 
-def build_workload(scene, width, height, spp, monte_carlo=1):
+STAND_INS = {"sponza": "sponza_syn", "helmet": "helmet_syn", "lotus": "lotus_syn"}
+
+
+def build_workload(scene, width, height, spp, monte_carlo=1, scene_root=None):
+    """`scene`: a stand-in name (sponza_syn, helmet_syn, lotus_syn), a fixture under scenes/, or one of the reference's scene files
+    (e.g. scene/sponza.json) resolved against `scene_root` (a tree laid out like the reference's: scene/*.json, data/...).
+    A scene file is loaded for REAL when every asset it names is present there (the .glb of sponza / helmet / lotus under
+    data/temp/, which the reference downloads at load time: SURVEY.md 8d (i)); nothing is ever downloaded here.  When an asset
+    is missing the stand-in of the same name is rendered and labelled so.  fs.meta["data"] says which it was."""
     from rustray_amd import synthetic
     from rustray_amd.camera import Camera
     from rustray_amd.flat import make_config
     from tests.helpers import load_scene
-    if scene == "sponza_syn":
-        fs = synthetic.sponza_syn()
-    elif scene == "lotus_syn":
-        fs = synthetic.lotus_syn()
-    elif scene == "helmet_syn":
-        fs = synthetic.helmet_syn()
-    else:
-        fs = load_scene(scene)
+    fs = None
+    if scene.endswith(".json"):
+        from rustray_amd import scene as scene_mod
+        root = scene_root or os.environ.get("RUSTRAY_SCENE_ROOT") or os.getcwd()
+        why = None
+        try:
+            sc = scene_mod.load_scene([scene], width, height, root=root)
+            fs = sc.flatten()
+            fs.name = os.path.splitext(os.path.basename(scene))[0]
+            fs.meta = {"camera": sc.cam.state(), "config": sc.raytracing_config, "data": "real", "source": os.path.join(root, scene)}
+        except Exception as e:  # noqa: BLE001  (a missing asset, or a file the loader mirror cannot read)
+            why = f"{type(e).__name__}: {e}"
+        if fs is None:
+            base = os.path.splitext(os.path.basename(scene))[0]
+            scene = STAND_INS.get(base)
+            if scene is None:
+                raise SystemExit(f"{base}: cannot load the scene file ({why}) and there is no stand-in for it")
+            sys.stderr.write(f"bench.py: {base}: {why}; rendering the stand-in {scene}\n")
+    if fs is None:
+        if scene == "sponza_syn":
+            fs = synthetic.sponza_syn()
+        elif scene == "lotus_syn":
+            fs = synthetic.lotus_syn()
+        elif scene == "helmet_syn":
+            fs = synthetic.helmet_syn()
+        else:
+            fs = load_scene(scene)
+        fs.meta = dict(fs.meta)
+        fs.meta["data"] = "synthetic" if fs.meta.get("synthetic") else "fixture"
     st = dict(fs.meta["camera"])
     st["width"], st["height"] = width, height
     cam = Camera.from_state(st)
@@ -182,7 +211,7 @@ def one_process_main(args):
     if max(devices) >= n_dev:
         print(json.dumps({"error": f"{n} devices asked, {n_dev} visible"}), flush=True)
         return
-    fs, cam, cfg = build_workload(args.scene, args.width, args.height, args.spp, args.monte_carlo)
+    fs, cam, cfg = build_workload(args.scene, args.width, args.height, args.spp, args.monte_carlo, args.scene_root)
     camc = cam.c_struct()
     scenes = [capi.DeviceScene(fs, d) for d in devices]
     try:
@@ -219,7 +248,7 @@ def start_one_process_helper(args, world):
     """Started by rank 0 BEFORE it initialises the GPU (a process that has may not exec another program)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--one-process-helper", "--gpus", str(world), "--steps", str(max(1, min(args.steps, 5))),
-           "--warmup", "1", "--scene", args.scene, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp),
+           "--warmup", "1", "--scene", args.scene, *(["--scene-root", args.scene_root] if args.scene_root else []), "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp),
            "--monte-carlo", str(args.monte_carlo)]
     if args.rgba_only:
         cmd.append("--rgba-only")
@@ -256,7 +285,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="sponza_syn")
+    ap.add_argument("--scene", default="sponza_syn", help="stand-in or fixture name, or a reference scene file such as scene/sponza.json (see --scene-root)")
+    ap.add_argument("--scene-root", default=None, help="tree laid out like the reference's (scene/*.json, data/temp/*.glb): a scene file is rendered for real when "
+                                                       "its assets are present there, else its stand-in; nothing is downloaded")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--spp", type=int, default=128)
@@ -299,7 +330,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
 
-    fs, cam, cfg = build_workload(args.scene, args.width, args.height, args.spp, args.monte_carlo)
+    fs, cam, cfg = build_workload(args.scene, args.width, args.height, args.spp, args.monte_carlo, args.scene_root)
     tw, th = [int(v) for v in args.tile.split("x")]
     tf = TiledFrame(args.width, args.height, rank, world, tw, th)
     ds = capi.DeviceScene(fs, local_rank)  # scene replicated on every GPU, resident before timing
@@ -380,9 +411,10 @@ def main():
         result = {
             "metric": "Mrays/s", "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": fs.meta.get("data", "synthetic"),
             "config": {"workload": f"{fs.name} {args.width}x{args.height} {args.spp}spp monte_carlo={args.monte_carlo} max_recursion=6 "
-                                   "(synthetic stand-in for scene/sponza.json: the .glb asset is not available offline)",
+                                   + ("(the reference's own scene file and assets)" if fs.meta.get("data") == "real" else
+                                      "(synthetic stand-in for scene/sponza.json: the .glb asset is not available offline)" if fs.name == "sponza_syn" else f"({fs.meta.get('data')})"),
                        "outputs": "RGBA8 only (--rgba-only)" if args.rgba_only else "RGBA8 + normal + depth + object_id (PixelData), resident in HBM",
                        "items": len(fs.items), "triangles": fs.n_triangles_instanced(),
                        "tiling": f"{tw}x{th} tiles interleaved over {world} rank(s), one packed gather (RGBA8 + aux) to rank 0",

@@ -57,9 +57,6 @@ typedef enum rr_status {
  * 32767 samples on, and shuffles cell_size^2 cells; 16382 is the last count of the cell size below that
  * (cell_size 8192: a table of 8192^2 = 67 M cells, 268 MB of host memory while it is shuffled). */
 #define RR_MAX_SAMPLES 16382u
-/* rr_scene_create: more ENABLED lights than this are refused with RR_ERR_UNSUPPORTED (the shade kernel keeps one bit per
- * enabled light and lane; the reference has no limit, its scenes carry one to three lights). */
-#define RR_MAX_ENABLED_LIGHTS 32u
 
 /* TextureType order of reference src/shape/mod.rs:633-643. */
 enum {

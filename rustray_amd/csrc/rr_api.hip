@@ -335,6 +335,7 @@ static DMaterial make_dmaterial(const rr_material& m, const std::vector<uint32_t
     for (int k = 0; k < 3; k++) { d.ambient[k] = m.ambient_color[k]; d.base[k] = m.base_color[k]; d.specular[k] = m.specular_color[k]; }
     d.alpha = m.alpha; d.shininess = m.shininess; d.reflectivity = m.reflectivity; d.refraction_index = m.refraction_index;
     d.normal_map_strength = m.normal_map_strength; d.shadow_softness = m.shadow_softness; d.roughness = m.roughness;
+    d.cos_shadow_softness = rr_cos(m.shadow_softness * RR_PI_F); d.cos_roughness = rr_cos(m.roughness * RR_PI_F); // jitter()'s z_lo, see DMaterial
     bool any = false;
     uint32_t slots = 0u;
     for (int k = 0; k < RR_TEX_COUNT; k++) {
@@ -560,7 +561,6 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         dl[i].intensity = l.intensity; dl[i].max_angle = l.max_angle;
         dl[i].type = l.light_type | (l.enabled ? 0u : 0x80u);
         if (l.enabled) s->n_enabled_lights++;
-        if (s->n_enabled_lights > RR_MAX_ENABLED_LIGHTS) return fail(RR_ERR_UNSUPPORTED, "more than %u enabled lights", RR_MAX_ENABLED_LIGHTS);
     }
     HIP_TRY(s->lights.reserve(std::max<size_t>(dl.size(), 1) * sizeof(DLight)));
     if (!dl.empty()) HIP_TRY(hipMemcpy(s->lights.p, dl.data(), dl.size() * sizeof(DLight), hipMemcpyHostToDevice));
@@ -720,7 +720,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     HIP_TRY(upload(s->item_boxes, s->h_item_boxes.data(), s->h_item_boxes.size() * sizeof(float4)));
     HIP_TRY(upload(s->tris, all_tris.data(), all_tris.size() * sizeof(DTri)));
     if (all_trix.size() >= (1u << 26)) return fail(RR_ERR_UNSUPPORTED, "%zu triangles (addressed with 32-bit byte offsets)", all_trix.size());
-    static_assert(sizeof(DTriX) == 48 && sizeof(DNode4) == 128, "layouts the kernels address by byte offset");
+    static_assert(sizeof(DTriX) == 48 && sizeof(DNode4) == 128 && sizeof(DMaterial) == 112, "layouts the kernels address by byte offset");
     HIP_TRY(upload(s->trix, all_trix.data(), all_trix.size() * sizeof(DTriX)));
     HIP_TRY(upload(s->attrs, all_attrs.data(), all_attrs.size() * sizeof(DTriAttr)));
     HIP_TRY(upload(s->face_slot, all_face_slot.data(), all_face_slot.size() * 4));
@@ -1010,7 +1010,10 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
         s->arena_cap = M;
     }
     HIP_TRY(s->hit1.reserve(B * 16));
-    const uint64_t chunk = s->tuning.shade_chunk_rays ? std::max<uint64_t>(65536, s->tuning.shade_chunk_rays) : (64ull << 20);
+    // (the shadow queue holds one 48-B ray per hit of the chunk and ENABLED light: with many lights the chunk shrinks so that
+    // the queue stays within 16 GB -- the reference has no limit on lights, src/raytracing.rs:814)
+    const uint64_t chunk_by_lights = std::max<uint64_t>(65536, ((16ull << 30) / (48ull * std::max<uint32_t>(s->n_enabled_lights, 1u))) / (RR_BLOCK * RR_SQ_SHARDS) * (RR_BLOCK * RR_SQ_SHARDS));
+    const uint64_t chunk = std::min<uint64_t>(s->tuning.shade_chunk_rays ? std::max<uint64_t>(65536, s->tuning.shade_chunk_rays) : (64ull << 20), chunk_by_lights);
     // level 1: fixed shadow slots, (enabled light, hit of the chunk), the chunk padded to whole workgroup iterations;
     // deeper levels: the dense sharded queue (a shard's static share of the chunk, one slack group per shard)
     const uint64_t sq_need = std::max<uint64_t>(1, (std::min<uint64_t>(chunk, std::max<uint64_t>(M, B)) + RR_BLOCK * RR_SQ_SHARDS) * std::max<uint32_t>(s->n_enabled_lights, 1u));
@@ -1090,7 +1093,9 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
                 const int grid = (int)std::min<uint64_t>((c1 - c0 + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)shade_grid_max);
                 // level 1: shadow slots of this chunk = L x (the chunk padded to whole workgroup iterations), one validity word per 64
                 // (only where the shadow kernel's packet form applies: rr_kernels.hip, RR_BEAM_MIN_ITEMS .. RR_BEAM_MAX_ITEMS)
-                const bool sq_fixed = d == 1 && s->view.n_items >= RR_BEAM_MIN_ITEMS && s->view.n_items <= RR_BEAM_MAX_ITEMS;
+                // and up to RR_FIXED_SLOT_LIGHTS enabled lights: k_shade keeps one bit per light and lane for the validity words; more lights
+                // take the dense queue of the deeper levels, which has no such limit
+                const bool sq_fixed = d == 1 && s->view.n_items >= RR_BEAM_MIN_ITEMS && s->view.n_items <= RR_BEAM_MAX_ITEMS && L <= RR_FIXED_SLOT_LIGHTS;
                 const uint32_t sq_chunk_cap = sq_fixed ? (uint32_t)(((c1 - c0 + RR_BLOCK - 1) / RR_BLOCK) * RR_BLOCK) : 0u;
                 unsigned long long* sq_valid = s->sq_valid.as<unsigned long long>();
                 // deeper levels: shadow sub-queues, a shard gets the packets with (packet % RR_SQ_SHARDS == shard), L rays per hit at most
@@ -1641,6 +1646,10 @@ extern "C" int rr_trace_rays(rr_scene* s, const float* origins, const float* dir
 extern "C" int rr_math_probe(int op, const float* a, const float* b, const float* c, int n, float* out0, float* out1, float* out2,
                              uint64_t seed, int device) {
     if (n <= 0 || !a || !out0) return fail(RR_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (op == 6) { // the HOST build of rr_cos, as make_dmaterial uses it for DMaterial::cos_*: out0[i] = rr_cos(a[i] * pi); needs no device
+        for (int i = 0; i < n; i++) out0[i] = rr_cos(a[i] * RR_PI_F);
+        return RR_OK;
+    }
     HIP_TRY(hipSetDevice(device));
     DevBuf in[3], o[3];
     const float* src[3] = {a, b, c};

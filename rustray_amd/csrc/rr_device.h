@@ -83,7 +83,7 @@ struct DItem {
     int32_t root4;       // node index relative to node_base4, a leaf code, or RR_SENTINEL (no triangles)
 };
 
-// 96 B material record
+// 112 B material record (seven 16-B groups)
 struct DMaterial {
     float ambient[3]; float alpha;
     float base[3]; float shininess;
@@ -91,7 +91,10 @@ struct DMaterial {
     float refraction_index, normal_map_strength, shadow_softness, roughness;
     int32_t tex[8];
     uint32_t flags; // bit0 nearest filtering, bit1 receive_shadow, bit2 monte_carlo, bit3 any texture, bits 8..15 slot k holds a texture
-    uint32_t _pad[3];
+    // jitter()'s cone bound z_lo = cos(spread * pi) for the two spreads that are material constants, evaluated once on the host with the
+    // kernels' own rr_cos (src/raytracing.rs:590-596 computes it per call; a roughness MAP gives a per-hit spread and is evaluated per hit)
+    float cos_shadow_softness, cos_roughness;
+    uint32_t _pad;
 };
 enum : uint32_t { RR_MF_NEAREST = 1u, RR_MF_RECEIVE_SHADOW = 2u, RR_MF_MONTE_CARLO = 4u, RR_MF_ANY_TEX = 8u, RR_MF_TEX_SLOT0 = 256u };
 
@@ -116,7 +119,7 @@ struct DSceneView {
     const DLight* lights;
     uint32_t n_items;
     uint32_t n_lights;
-    uint32_t n_enabled_lights; // <= 32: one bit per enabled light in k_shade's per-lane "wrote a shadow ray" word
+    uint32_t n_enabled_lights; // any number; level 1 uses fixed shadow slots for up to RR_FIXED_SLOT_LIGHTS of them
     const DNode4* tnodes4;  // the top level over item world boxes, same form (one item per leaf)
     int32_t tlas_root4;      // node index, a leaf code (one item), or RR_SENTINEL (empty scene)
     const float4* item_boxes; // the same padded world boxes per item: [2 i] = lo, [2 i + 1] = hi (the packet form of the top level, trace_closest_packet)

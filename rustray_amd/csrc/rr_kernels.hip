@@ -24,6 +24,7 @@
 
 #define RR_BLOCK 256
 #define RR_SQ_SHARDS 32 // sub-queues of the shadow queue, one append counter each
+#define RR_FIXED_SLOT_LIGHTS 32u // level 1 keeps fixed shadow slots for up to this many enabled lights (one bit per light in k_shade's sq_wrote)
 #ifndef RR_SQ_STRIDE
 #define RR_SQ_STRIDE 16 // words between two append counters: 64 B apart (packed into one line they cost k_shade 13-20 %)
 #endif
@@ -915,19 +916,20 @@ RR_DEV float4 tex_bilinear(const DSceneView& sc, const DTexture& t, float u, flo
 struct MatR {
     f3 ambient, base, specular;
     float alpha, shininess, reflectivity, refraction_index, normal_map_strength, shadow_softness, roughness;
+    float cos_shadow_softness, cos_roughness; // jitter()'s z_lo for the two constant spreads (host-evaluated, DMaterial)
     uint32_t flags;
     const DMaterial* p;
     const float* lut; // u8 -> f32 table of the workgroup (LDS)
 };
 RR_DEV MatR load_material(const DMaterial* p, const float* lut) {
     const float4* q = (const float4*)p;
-    const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+    const float4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[6]; // q[4], q[5]: the texture slots, read when a slot's flag is set
     MatR m;
     m.ambient = mk3(a.x, a.y, a.z); m.alpha = a.w;
     m.base = mk3(b.x, b.y, b.z); m.shininess = b.w;
     m.specular = mk3(c.x, c.y, c.z); m.reflectivity = c.w;
     m.refraction_index = d.x; m.normal_map_strength = d.y; m.shadow_softness = d.z; m.roughness = d.w;
-    m.flags = p->flags; m.p = p; m.lut = lut;
+    m.flags = __float_as_uint(e.x); m.cos_shadow_softness = e.y; m.cos_roughness = e.z; m.p = p; m.lut = lut;
     return m;
 }
 RR_DEV bool tex_color(const DSceneView& sc, const MatR& m, bool has_uv, f2 uv, int slot, float4* out) {
@@ -984,13 +986,14 @@ RR_DEV f2 mesh_uv(const DSceneView& sc, const DItem& it, uint32_t slot, f3 hit, 
 // jitter (reference src/raytracing.rs:565-626) on the counter-based generator
 // ---------------------------------------------------------------------------
 struct RngKey { uint32_t seed_lo, seed_hi, pixel, sample, node; };
-RR_DEV f3 jitter(f3 dir, float spread, const RngKey& k, uint32_t stream) {
+// z_lo = rr_cos(spread * RR_PI_F): passed in, because for the two spreads that are material constants (shadow_softness, roughness
+// without a map) the host has evaluated it once per material (DMaterial::cos_*) with the same rr_cos
+RR_DEV f3 jitter(f3 dir, float spread, float z_lo, const RngKey& k, uint32_t stream) {
     if (spread <= 0.0f) return dir;
     f3 b3 = normalize3(dir);
     f3 diff = (rr_abs(b3.x) < 0.5f) ? mk3(1.0f, 0.0f, 0.0f) : mk3(0.0f, 1.0f, 0.0f);
     f3 b1 = normalize3(cross3(b3, diff));
     f3 b2 = cross3(b1, b3);
-    float z_lo = rr_cos(spread * RR_PI_F);
     if (!(z_lo < 1.0f)) return dir;
     uint32_t r0, r1;
     philox4x32_10(k.pixel, k.sample, k.node, stream, k.seed_lo, k.seed_hi, &r0, &r1);
@@ -1026,6 +1029,17 @@ RR_DEV long long to_fix(float v, float scale, float clampv) {
     v = fminf(fmaxf(v, -clampv), clampv);
     return __float2ll_rn(v * scale);
 }
+// The fixed-point sum of one lane and channel is a 32-bit integer.  Nearly every term is small (a colour term up to 2, a normal
+// component, a depth below 512: |v * scale| < 2^25) and converts with v_rndne + v_cvt_i32; __float2ll_rn is eleven instructions and
+// a 64-bit add two more, seven to ten times per shaded hit.  A term beyond 2^25 goes straight to its accumulator word as one 64-bit
+// atomic of its own (rare: a saturating highlight, a far hit's depth); a NaN adds nothing (its pixel is flagged).  Every term is
+// rounded to nearest-even by itself either way, and integer adds commute: the pixel's sum is the same integer.
+RR_DEV void fix_add(int& n, float v, float scale, float clampv, long long* plane, uint32_t pix) {
+    const float x = v * scale;
+    if (rr_abs(x) < 33554432.0f) n += __float2int_rn(x); // (inside every clamp in use: |v| < 2 at scale 2^24, < 512 at 2^16)
+    else { const long long t = to_fix(v, scale, clampv); if (t != 0ll && plane) atomicAdd((unsigned long long*)plane + pix, (unsigned long long)t); }
+}
+
 // A colour contribution of channel `ch`: non-finite values are recorded in `flags` (RR_NF_*), because the reference's f32
 // sum would carry them to the pixel (NaN or +inf -> 255, -inf -> 0, src/raytracing.rs:406-417) while a fixed-point sum cannot.
 RR_DEV uint32_t nonfinite_flags(float r, float g, float b) {
@@ -1080,14 +1094,13 @@ template <int N> RR_DEV bool wave_merge_runs32(uint32_t pix, int (&v)[N]) {
     const int next_head = RR_DPP_SHL(head, 1);
     return (lane16 == 15u || next_head != 0) && pix != 0xffffffffu;
 }
-RR_DEV bool fits25(long long a, long long b, long long c) { // |a|, |b|, |c| < 2^25
-    const unsigned long long m = (unsigned long long)(a + (1ll << 25)) | (unsigned long long)(b + (1ll << 25)) | (unsigned long long)(c + (1ll << 25));
-    return (m >> 26) == 0ull;
+RR_DEV bool fits25i(int a, int b, int c) { // |a|, |b|, |c| < 2^25
+    return (((uint32_t)(a + (1 << 25)) | (uint32_t)(b + (1 << 25)) | (uint32_t)(c + (1 << 25))) >> 26) == 0u;
 }
-RR_DEV void accum_merged(const DAccum& acc, uint32_t pix, long long r, long long g, long long b) {
+RR_DEV void accum_merged(const DAccum& acc, uint32_t pix, int r, int g, int b) {
     unsigned long long* p = (unsigned long long*)acc.rgb + pix; // one plane per channel
-    if (__ballot(!fits25(r, g, b)) == 0ull) {
-        int w[3] = {(int)r, (int)g, (int)b};
+    if (__ballot(!fits25i(r, g, b)) == 0ull) {
+        int w[3] = {r, g, b};
         if (wave_merge_runs32<3>(pix, w)) {
             if (w[0]) atomicAdd(p, (unsigned long long)(long long)w[0]);
             if (w[1]) atomicAdd(p + acc.n, (unsigned long long)(long long)w[1]);
@@ -1095,7 +1108,7 @@ RR_DEV void accum_merged(const DAccum& acc, uint32_t pix, long long r, long long
         }
         return;
     }
-    unsigned long long v[3] = {(unsigned long long)r, (unsigned long long)g, (unsigned long long)b};
+    unsigned long long v[3] = {(unsigned long long)(long long)r, (unsigned long long)(long long)g, (unsigned long long)(long long)b};
     if (wave_merge_runs<3>(pix, v)) {
         if (v[0]) atomicAdd(p, v[0]);
         if (v[1]) atomicAdd(p + acc.n, v[1]);
@@ -1105,22 +1118,21 @@ RR_DEV void accum_merged(const DAccum& acc, uint32_t pix, long long r, long long
 // The aux outputs of the root hits (normal and depth sums, reference src/raytracing.rs:400-402), merged the same way:
 // the samples of a pixel sit in neighbouring lanes, and 64 lanes adding to one address serialise in the L2 atomic
 // units (measured: k_shade 6.5 -> 42.8 ms on sponza_syn when the four aux adds of every primary hit went out unmerged).
-RR_DEV void accum_aux_merged(const DAccum& acc, uint32_t pix, long long nx, long long ny, long long nz, long long depth) {
-    if (__ballot(!fits25(nx, ny, nz)) == 0ull) { // the normal in 32 bits, the depth (x 2^16: up to 2^46) in 64
-        int w[3] = {(int)nx, (int)ny, (int)nz};
-        unsigned long long d[1] = {(unsigned long long)depth};
-        const bool last32 = wave_merge_runs32<3>(pix, w);
-        const bool last64 = wave_merge_runs<1>(pix, d);
-        if (last32 && acc.normal) {
-            unsigned long long* np = (unsigned long long*)acc.normal + pix;
-            if (w[0]) atomicAdd(np, (unsigned long long)(long long)w[0]);
-            if (w[1]) atomicAdd(np + acc.n, (unsigned long long)(long long)w[1]);
-            if (w[2]) atomicAdd(np + 2ull * acc.n, (unsigned long long)(long long)w[2]);
+RR_DEV void accum_aux_merged(const DAccum& acc, uint32_t pix, int nx, int ny, int nz, int depth) {
+    if (__ballot(!fits25i(nx, ny, nz) || !fits25i(depth, 0, 0)) == 0ull) {
+        int w[4] = {nx, ny, nz, depth};
+        if (wave_merge_runs32<4>(pix, w)) {
+            if (acc.normal) {
+                unsigned long long* np = (unsigned long long*)acc.normal + pix;
+                if (w[0]) atomicAdd(np, (unsigned long long)(long long)w[0]);
+                if (w[1]) atomicAdd(np + acc.n, (unsigned long long)(long long)w[1]);
+                if (w[2]) atomicAdd(np + 2ull * acc.n, (unsigned long long)(long long)w[2]);
+            }
+            if (acc.depth && w[3]) atomicAdd((unsigned long long*)acc.depth + pix, (unsigned long long)(long long)w[3]);
         }
-        if (last64 && acc.depth && d[0]) atomicAdd((unsigned long long*)acc.depth + pix, d[0]);
         return;
     }
-    unsigned long long v[4] = {(unsigned long long)nx, (unsigned long long)ny, (unsigned long long)nz, (unsigned long long)depth};
+    unsigned long long v[4] = {(unsigned long long)(long long)nx, (unsigned long long)(long long)ny, (unsigned long long)(long long)nz, (unsigned long long)(long long)depth};
     if (wave_merge_runs<4>(pix, v)) {
         if (acc.normal) {
             unsigned long long* np = (unsigned long long*)acc.normal + pix;
@@ -1376,13 +1388,13 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
         const uint32_t shard = ((base - chunk_begin) / RR_BLOCK) % RR_SQ_SHARDS; // the 4 packets of a workgroup iteration stay together
         uint32_t* const sq_count = sq_counts + shard * RR_SQ_STRIDE;
         const uint32_t sq_base = shard * sq_segcap;
-        long long sum_r = 0, sum_g = 0, sum_b = 0; // this hit's direct adds, merged with its neighbours' at the end
+        int sum_r = 0, sum_g = 0, sum_b = 0; // this hit's direct adds (32-bit fixed point, fix_add), merged with its neighbours' at the end
         // children of this hit (emitted after the hit is shaded, by all waves of the workgroup together)
         bool spawn_refl = false, spawn_refr = false;
         float4 c1_r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1_r1 = c1_r0, c2_r0 = c1_r0, c2_r1 = c1_r0;
         uint2 c1_r2 = make_uint2(0u, 0u), c2_r2 = c1_r2;
         uint32_t sum_pix = 0xffffffffu, aux_pix = 0xffffffffu, nf = 0u, pix_of_nf = 0u;
-        long long aux_nx = 0, aux_ny = 0, aux_nz = 0, aux_d = 0;
+        int aux_nx = 0, aux_ny = 0, aux_nz = 0, aux_d = 0;
         if (active) {
         n_shaded++;
         float4 r0, r1; uint2 r2;
@@ -1442,8 +1454,10 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
         // ---- aux outputs of the root node (:742-744, :400-402): summed per pixel below, with the wave's other root hits
         if (depth == 1u) {
             aux_pix = pix;
-            aux_d = to_fix(hit_dist, RR_DEPTH_SCALE, 1.0e9f);
-            aux_nx = to_fix(normal.x, RR_FIX_SCALE, RR_FIX_CLAMP); aux_ny = to_fix(normal.y, RR_FIX_SCALE, RR_FIX_CLAMP); aux_nz = to_fix(normal.z, RR_FIX_SCALE, RR_FIX_CLAMP);
+            fix_add(aux_d, hit_dist, RR_DEPTH_SCALE, 1.0e9f, acc.depth, pix);
+            fix_add(aux_nx, normal.x, RR_FIX_SCALE, RR_FIX_CLAMP, acc.normal, pix);
+            fix_add(aux_ny, normal.y, RR_FIX_SCALE, RR_FIX_CLAMP, acc.normal ? acc.normal + acc.n : nullptr, pix);
+            fix_add(aux_nz, normal.z, RR_FIX_SCALE, RR_FIX_CLAMP, acc.normal ? acc.normal + 2ull * acc.n : nullptr, pix);
             if ((normal.x - normal.x) + (normal.y - normal.y) + (normal.z - normal.z) + (hit_dist - hit_dist) != 0.0f) { // rare: something is not finite
                 if (hit_dist != hit_dist) nf |= RR_NF_DEPTH_NAN;
                 if (normal.x != normal.x) nf |= RR_NF_NORMAL_NAN;
@@ -1487,9 +1501,9 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
         {
             bool has_rtc = tex_color(sc, m, has_uv, uv, 5, &tc);
             if (mc && (m.roughness > 0.0f || has_rtc)) {
-                float roughness = m.roughness;
-                if (has_rtc) roughness = (1.0f / RR_PI_F / 2.0f) * tc.x;
-                surface_normal = jitter(surface_normal, roughness, rk, 0u);
+                float roughness = m.roughness, z_lo = m.cos_roughness;
+                if (has_rtc) { roughness = (1.0f / RR_PI_F / 2.0f) * tc.x; z_lo = rr_cos(roughness * RR_PI_F); }
+                surface_normal = jitter(surface_normal, roughness, z_lo, rk, 0u);
             }
         }
         // ---- colours and alpha (:801-811)
@@ -1546,7 +1560,8 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
             sum_pix = pix;
             const float kr_ = thr * (fr.fog_color[0] * fa + ambient_color.x), kg_ = thr * (fr.fog_color[1] * fa + ambient_color.y), kb_ = thr * (fr.fog_color[2] * fa + ambient_color.z);
             nf |= nonfinite_flags(kr_, kg_, kb_);
-            sum_r += to_fix(kr_, RR_FIX_SCALE, RR_FIX_CLAMP); sum_g += to_fix(kg_, RR_FIX_SCALE, RR_FIX_CLAMP); sum_b += to_fix(kb_, RR_FIX_SCALE, RR_FIX_CLAMP);
+            fix_add(sum_r, kr_, RR_FIX_SCALE, RR_FIX_CLAMP, acc.rgb, pix); fix_add(sum_g, kg_, RR_FIX_SCALE, RR_FIX_CLAMP, acc.rgb + acc.n, pix);
+            fix_add(sum_b, kb_, RR_FIX_SCALE, RR_FIX_CLAMP, acc.rgb + 2ull * acc.n, pix);
         }
         // ---- object id (:744, :966-969): the last sample's id, passed through fully transparent hits
         const bool child_idc = idc && spawn_refr && approx_equal(alpha, 0.0f);
@@ -1592,14 +1607,21 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
             const bool want_shadow = (m.flags & RR_MF_RECEIVE_SHADOW) != 0u && (nonzero || sc.any_alpha_occluder != 0u);
             if (!(m.flags & RR_MF_RECEIVE_SHADOW) && nonzero) {
                 nf |= nonfinite_flags(cr, cg, cb);
-                sum_r += to_fix(cr, RR_FIX_SCALE, RR_FIX_CLAMP); sum_g += to_fix(cg, RR_FIX_SCALE, RR_FIX_CLAMP); sum_b += to_fix(cb, RR_FIX_SCALE, RR_FIX_CLAMP);
+                fix_add(sum_r, cr, RR_FIX_SCALE, RR_FIX_CLAMP, acc.rgb, pix); fix_add(sum_g, cg, RR_FIX_SCALE, RR_FIX_CLAMP, acc.rgb + acc.n, pix);
+                fix_add(sum_b, cb, RR_FIX_SCALE, RR_FIX_CLAMP, acc.rgb + 2ull * acc.n, pix);
+                if ((lk & 31u) == 31u) { // (hundreds of unshadowed lights: the 32-bit sums are flushed before they can overflow)
+                    if (sum_r) atomicAdd((unsigned long long*)acc.rgb + pix, (unsigned long long)(long long)sum_r);
+                    if (sum_g) atomicAdd((unsigned long long*)acc.rgb + acc.n + pix, (unsigned long long)(long long)sum_g);
+                    if (sum_b) atomicAdd((unsigned long long*)acc.rgb + 2ull * acc.n + pix, (unsigned long long)(long long)sum_b);
+                    sum_r = sum_g = sum_b = 0;
+                }
             }
             const uint32_t si = sq_fixed ? lk * sq_cap + sq_slot : sq_base + wave_alloc(sq_count, want_shadow, lane);
             if (want_shadow) {
-                sq_wrote |= 1u << lk;
+                if (sq_fixed) sq_wrote |= 1u << lk; // (fixed slots are only chosen for <= RR_FIXED_SLOT_LIGHTS enabled lights)
                 f3 so = hit_point + (surface_normal * 0.001f);
                 f3 sd = to_light;
-                if (mc) sd = jitter(sd, m.shadow_softness, rk, 1u + li);
+                if (mc) sd = jitter(sd, m.shadow_softness, m.cos_shadow_softness, rk, 1u + li);
                 sq.s0[si] = make_float4(so.x, so.y, so.z, limit);
                 sq.s1[si] = make_float4(sd.x, sd.y, sd.z, __uint_as_float((uint32_t)item_idx | (depth << 27)));
                 sq.s2[si] = make_float4(cr, cg, cb, __uint_as_float(pix));
@@ -1734,7 +1756,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADOW_WAVES) void k_trace_shadow(DSce
         else { const uint32_t left = n - p * RR_WAVE; valid = left >= RR_WAVE ? ~0ull : (1ull << left) - 1ull; }
         if (valid == 0ull) continue;
         {
-        long long sum_r = 0, sum_g = 0, sum_b = 0;
+        int sum_r = 0, sum_g = 0, sum_b = 0;
         uint32_t sum_pix = 0xffffffffu;
         const bool live = ((valid >> lane) & 1ull) != 0ull;
         {
@@ -1775,7 +1797,8 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADOW_WAVES) void k_trace_shadow(DSce
             sum_pix = __float_as_uint(s2.w);
             const float vr_ = s2.x * factor, vg_ = s2.y * factor, vb_ = s2.z * factor;
             const uint32_t nf = nonfinite_flags(vr_, vg_, vb_);
-            sum_r = to_fix(vr_, RR_FIX_SCALE, RR_FIX_CLAMP); sum_g = to_fix(vg_, RR_FIX_SCALE, RR_FIX_CLAMP); sum_b = to_fix(vb_, RR_FIX_SCALE, RR_FIX_CLAMP);
+            fix_add(sum_r, vr_, RR_FIX_SCALE, RR_FIX_CLAMP, acc.rgb, sum_pix); fix_add(sum_g, vg_, RR_FIX_SCALE, RR_FIX_CLAMP, acc.rgb + acc.n, sum_pix);
+            fix_add(sum_b, vb_, RR_FIX_SCALE, RR_FIX_CLAMP, acc.rgb + 2ull * acc.n, sum_pix);
             if (nf) atomicOr(&acc.flags[sum_pix], nf);
             }
         }
@@ -1999,7 +2022,8 @@ __global__ __launch_bounds__(RR_BLOCK) void k_post_process(uint32_t width, uint3
 
 // ---------------------------------------------------------------------------
 // kernel 8: device self-test of the arithmetic contract (tests/test_device_math.py)
-// op: 0 sincos -> (sin, cos); 1 acos; 2 atan2(a, b); 3 a / b; 4 sqrt(a); 5 jitter(dir = (a, b, c))
+// op: 0 sincos -> (sin, cos); 1 acos; 2 atan2(a, b); 3 a / b; 4 sqrt(a); 5 jitter(dir = (a, b, c)); 7 cos(a * pi) as jitter() needs it
+// (op 6 is the HOST build of the same rr_cos, rr_api.hip)
 // ---------------------------------------------------------------------------
 __global__ void k_math_probe(int op, const float* a, const float* b, const float* c, int n, float* out0, float* out1, float* out2,
                              uint32_t seed_lo, uint32_t seed_hi) {
@@ -2010,9 +2034,10 @@ __global__ void k_math_probe(int op, const float* a, const float* b, const float
     else if (op == 2) out0[i] = rr_atan2(a[i], b[i]);
     else if (op == 3) out0[i] = a[i] / b[i];
     else if (op == 4) out0[i] = sqrtf(a[i]);
+    else if (op == 7) out0[i] = rr_cos(a[i] * RR_PI_F);
     else if (op == 5) {
         RngKey k; k.seed_lo = seed_lo; k.seed_hi = seed_hi; k.pixel = (uint32_t)i; k.sample = (uint32_t)(i & 7); k.node = 1u + (uint32_t)(i % 5);
-        f3 r = jitter(mk3(a[i], b[i], c[i]), 0.05f, k, (uint32_t)(i % 3));
+        f3 r = jitter(mk3(a[i], b[i], c[i]), 0.05f, rr_cos(0.05f * RR_PI_F), k, (uint32_t)(i % 3));
         out0[i] = r.x; out1[i] = r.y; out2[i] = r.z;
     }
 }

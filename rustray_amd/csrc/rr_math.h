@@ -18,6 +18,9 @@
 #include <stdint.h>
 
 #define RR_DEV __device__ __forceinline__
+// also callable from the host side of rr_api.hip (per-material constants that the kernels would otherwise re-derive per hit);
+// host and device evaluate the same IEEE binary32 sequence (-ffp-contract=off on both sides): tests/test_gpu_math.py compares them bit for bit
+#define RR_HD __host__ __device__ __forceinline__
 #define RR_FLT_MAX 3.40282347e+38f
 #define RR_PI_F 3.14159265358979323846f
 
@@ -38,15 +41,15 @@ RR_DEV f3 cross3(f3 a, f3 b) {
 RR_DEV float norm3(f3 a) { return sqrtf(dot3(a, a)); }
 RR_DEV f3 normalize3(f3 a) { return a / norm3(a); }
 
-RR_DEV uint32_t f_bits(float f) { return __float_as_uint(f); }
-RR_DEV float bits_f(uint32_t u) { return __uint_as_float(u); }
-RR_DEV float rr_abs(float a) { return bits_f(f_bits(a) & 0x7fffffffu); }
+RR_HD uint32_t f_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+RR_HD float bits_f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+RR_HD float rr_abs(float a) { return bits_f(f_bits(a) & 0x7fffffffu); }
 // Rust f32::max / min: the non-NaN operand wins
 RR_DEV float rs_max(float a, float b) { return (a > b || b != b) ? a : b; }
 RR_DEV float rs_min(float a, float b) { return (a < b || b != b) ? a : b; }
 
 // Rust `as` casts from f32: truncate, saturate, NaN -> 0
-RR_DEV int32_t as_i32(float f) {
+RR_HD int32_t as_i32(float f) {
     if (f != f) return 0;
     if (f >= 2147483648.0f) return 2147483647;
     if (f <= -2147483648.0f) return (-2147483647 - 1);
@@ -77,7 +80,7 @@ RR_DEV float row4(float4 r, float x, float y, float z, float w) {
 }
 
 // ---- sin / cos (Cephes sinf.c / cosf.c), |x| <= 8192 within 2 ulp -----------------
-RR_DEV void rr_sincos(float xin, float* s_out, float* c_out) {
+RR_HD void rr_sincos(float xin, float* s_out, float* c_out) {
     const float FOPI = 1.27323954473516f;
     const float DP1 = 0.78515625f;
     const float DP2 = 2.4187564849853515625e-4f;
@@ -102,7 +105,7 @@ RR_DEV void rr_sincos(float xin, float* s_out, float* c_out) {
     *s_out = neg_s ? -s : s;
     *c_out = neg_c ? -c : c;
 }
-RR_DEV float rr_cos(float x) { float s, c; rr_sincos(x, &s, &c); return c; }
+RR_HD float rr_cos(float x) { float s, c; rr_sincos(x, &s, &c); return c; }
 
 // ---- asin / acos (Cephes asinf.c) ------------------------------------------------------
 RR_DEV float rr_asin(float xx) {

@@ -55,3 +55,12 @@ def test_jitter_bit_exact(hip, oracle):
     for i in range(0, n, 37):
         oracle.lib().rro_jitter(_p(d[i].copy()), 0.05, seed, i, i & 7, 1 + i % 5, i % 3, _p(out))
         assert (out[0], out[1], out[2]) == (gx[i], gy[i], gz[i])
+
+
+def test_host_and_device_builds_of_rr_cos_agree(hip):
+    """DMaterial::cos_* (host) is used where jitter() computed cos(spread * pi) per call (device): the two builds, bit for bit."""
+    rng = np.random.default_rng(12)
+    x = np.concatenate([rng.uniform(0.0, 1.0, 200000), rng.uniform(-4.0, 40.0, 50000), [0.0, 0.01, 0.015, 0.02, 0.5, 1.0]]).astype(np.float32)
+    host, _, _ = hip.math_probe(6, x)
+    dev, _, _ = hip.math_probe(7, x)
+    assert np.array_equal(host.view(np.uint32), dev.view(np.uint32))

@@ -36,16 +36,38 @@ def test_many_items_several_lights_fixed_shadow_slots(hip, oracle, seed):
     assert st["shadow_rays"] > 0 and st["shadow_rays"] <= ref["counters"]["rays_shadow"]
 
 
-def test_more_than_32_enabled_lights_is_refused(hip):
+def test_any_number_of_lights(hip, oracle):
+    """The reference loops over scene.lights without a limit (src/raytracing.rs:814).  Up to 32 enabled lights level 1 keeps fixed
+    shadow slots (one validity bit per light and lane); 40 enabled lights (of 44: every eleventh disabled, its slot still counts
+    as an RNG stream) take the dense queue of the deeper levels.  Both against the oracle, and 32 | 33 lights against each other
+    on the lights they share."""
     import copy
     fs = _scene(9119)
-    fs.lights = [copy.copy(fs.lights[0]) for _ in range(33)]
-    for l in fs.lights:
-        l.enabled = True
-    with pytest.raises(hip.RustrayHipError) as e:
-        hip.DeviceScene(fs, 0)
-    assert "32" in str(e.value)
-    fs.lights = fs.lights[:32]
-    with hip.DeviceScene(fs, 0) as ds:
-        out = ds.render(camera_for(fs, 32, 24).c_struct(), make_config(samples=1, monte_carlo=False, seed=0, max_recursion=1))
-    assert out["rgba"].shape == (24, 32, 4)
+    assert len(fs.items) >= 17
+    rng = np.random.default_rng(40)
+    proto = fs.lights[0]
+    lights = []
+    for i in range(44):
+        l = copy.copy(proto)
+        l.pos = tuple(float(v) for v in (np.asarray(proto.pos) + rng.uniform(-3.0, 3.0, 3)))
+        l.color = tuple(float(v) for v in rng.uniform(0.2, 1.0, 3))
+        l.intensity = float(proto.intensity) / 12.0
+        l.light_type = int(i % 3)
+        l.max_angle = 1.0
+        l.enabled = (i % 11) != 10
+        lights.append(l)
+    cam = camera_for(fs, 48, 32).c_struct()
+    cfg = make_config(samples=2, monte_carlo=True, seed=77, max_recursion=3)
+    for n_lights in (44, 35):   # 40 and 32 enabled
+        fs.lights = lights[:n_lights]
+        n_on = sum(1 for l in fs.lights if l.enabled)
+        with hip.DeviceScene(fs, 0) as ds:
+            a = ds.render(cam, cfg)
+            st = ds.stats()
+            ds.set_tuning(shade_chunk_rays=65536, queue_budget_bytes=1)
+            b = ds.render(cam, cfg)
+        assert np.array_equal(a["rgba"], b["rgba"])
+        ref = oracle.render(fs.c_struct(), cam, cfg, n_threads=8, want_counters=True)
+        res = compare_frames(a, ref)
+        assert res["n_rgb_over"] == 0 and res["n_id_diff"] == 0 and res["nan_mismatch"] == 0, (n_on, res)
+        assert 0 < st["shadow_rays"] <= ref["counters"]["rays_shadow"] and st["shaded_hits"] == ref["counters"]["shaded_hits"], n_on

@@ -175,3 +175,24 @@ def test_animation_mirror():
     assert not Animation.from_json({"fps": 25, "enabled": True, "keyframes": [{"time": 0, "objects": []}]}).has_animation()
     back = Animation.from_meta(an.to_meta())
     assert np.array_equal(back.get_trans_for_frame(10, "helmet"), an.get_trans_for_frame(10, "helmet"))
+
+
+def test_bench_scene_file_is_real_when_its_assets_are_present_and_the_stand_in_otherwise(tmp_path, capsys):
+    """bench.py --scene <scene file> --scene-root <tree>: a reference scene file is rendered for real when every
+    asset it names is present under the root; when the .glb the reference would download is missing, the stand-in of the same
+    name is rendered and labelled synthetic.  Nothing is downloaded either way."""
+    import json
+    import bench
+    (tmp_path / "scene").mkdir()
+    (tmp_path / "scene" / "mini.json").write_text(json.dumps({
+        "name": "mini", "camera": {"pos": {"x": 0, "y": 0, "z": 5}, "fov": 60},
+        "lights": [{"light_type": "point", "pos": {"x": 0, "y": 4, "z": 2}, "color": {"r": 1, "g": 1, "b": 1}, "intensity": 50.0}],
+        "objects": [{"type": "sphere", "name": "ball", "radius": 1.0, "pos": {"x": 0, "y": 0, "z": 0}, "reflectivity": 0.3}]}))
+    (tmp_path / "scene" / "sponza.json").write_text(json.dumps({
+        "name": "Sponza", "objects": [{"name": "sponza", "type": "gltf", "url": "https://example.invalid/Sponza_fixed.glb",
+                                      "path": "data/temp/Sponza_fixed.glb", "texture_filtering_nearest": True}]}))
+    fs, cam, cfg = bench.build_workload("scene/mini.json", 64, 36, 2, 1, str(tmp_path))
+    assert fs.meta["data"] == "real" and fs.name == "mini" and len(fs.items) == 1 and cam.width == 64 and cfg.samples == 2
+    fs, cam, cfg = bench.build_workload("scene/sponza.json", 64, 36, 2, 1, str(tmp_path))
+    assert fs.meta["data"] == "synthetic" and fs.name == "sponza_syn" and len(fs.items) > 50
+    assert "Sponza_fixed.glb" in capsys.readouterr().err

@@ -50,3 +50,19 @@ def test_atan2_within_2ulp_and_quadrants(oracle):
     o = np.zeros(5, np.float32)
     oracle.lib().rro_atan2(sp_y.ctypes.data_as(C.c_void_p), sp_x.ctypes.data_as(C.c_void_p), 5, o.ctypes.data_as(C.c_void_p))
     assert np.allclose(o, [0.0, np.pi, np.pi / 2, -np.pi / 2, -np.pi], atol=1e-7)
+
+
+def test_host_build_of_rr_cos_equals_the_oracles(oracle):
+    """make_dmaterial evaluates jitter()'s cone bound cos(spread * pi) once per material on the HOST with the kernels' own rr_cos
+    (rr_math.h, host + device).  Its host build against the oracle's cosine, bit for bit, over the spreads a material can hold."""
+    import ctypes as C
+    from rustray_amd import capi
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(0.0, 1.0, 200000), rng.uniform(-4.0, 40.0, 50000), [0.0, 0.01, 0.015, 0.02, 0.5, 1.0, 1e-9]]).astype(np.float32)
+    got = np.zeros_like(x)
+    L = capi.lib()
+    assert L.rr_math_probe(6, x.ctypes.data_as(C.c_void_p), None, None, len(x), got.ctypes.data_as(C.c_void_p), None, None, C.c_uint64(0), 0) == 0
+    arg = (x * np.float32(np.pi)).astype(np.float32)   # the same single f32 multiply
+    s, c = np.zeros_like(arg), np.zeros_like(arg)
+    oracle.lib().rro_sincos(arg.ctypes.data_as(C.c_void_p), len(arg), s.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(got.view(np.uint32), c.view(np.uint32))

@@ -5,6 +5,7 @@
 set -e
 tag=$1; tmo=$2; shift 2
 root=$(cd "$(dirname "$0")/.." && pwd)
+rm -rf $root/build/snap_*   # one call at a time: earlier snapshots are on their boxes already
 snap=$root/build/snap_$tag
 rm -rf $snap; mkdir -p $snap
 tar -C $root --exclude=./.git --exclude=./gpurun_out --exclude='./build/snap_*' --exclude=__pycache__ --exclude=.pytest_cache -cf - . | tar -C $snap -xf -
