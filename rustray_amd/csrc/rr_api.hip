@@ -76,7 +76,7 @@ struct DevBuf {
 };
 
 struct TimedLaunch { hipEvent_t a, b; int kind; };
-struct ItemHost { uint32_t kind; int32_t material, material_cache; bool visible, flip_normals, mesh_has_normals; };
+struct ItemHost { uint32_t kind; int32_t material, material_cache; bool visible, flip_normals, mesh_has_normals, mesh_degenerate; };
 
 struct rr_scene {
     int device = 0;
@@ -358,8 +358,11 @@ static uint32_t item_flags(const ItemHost& it, const rr_material& cache, const r
     if (cache.reflection_only) f |= RR_IF_CACHE_REFL_ONLY;
     if (!(cache.alpha < 1.0f) && cache.backface_cullig) f |= RR_IF_SOLID_BASE; // the cache never has textures
     if (full.texture[RR_TEX_ALPHA] >= 0 && tex_width[full.texture[RR_TEX_ALPHA]] > 0) f |= RR_IF_OCCLUDER_ALPHA_TEX;
-    if (it.kind == RR_ITEM_SPHERE) f |= RR_IF_SPHERE;
-    else if (cache.smooth_shading && it.mesh_has_normals) f |= RR_IF_SMOOTH;
+    if (it.kind == RR_ITEM_SPHERE) f |= RR_IF_SPHERE | RR_IF_UV_MAY_BE_NAN;
+    else {
+        if (cache.smooth_shading && it.mesh_has_normals) f |= RR_IF_SMOOTH;
+        if (it.mesh_degenerate) f |= RR_IF_UV_MAY_BE_NAN;
+    }
     return f;
 }
 
@@ -571,7 +574,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     s->tlas_depth_limit = (int)std::min<uint32_t>(RR_TLAS_MAX_DEPTH, std::max<uint32_t>(1u, fs->n_items > 1 ? fs->n_items - 1 : 1u));
     s->blas_depth_limit = RR_STACK_DEPTH - 3 - s->tlas_depth_limit;
     // ---- meshes: one BLAS per mesh, shared by every item that names it
-    struct MeshDev { uint32_t tri_base, n_tris; uint32_t node_base4; int32_t root4; bool has_normals; };
+    struct MeshDev { uint32_t tri_base, n_tris; uint32_t node_base4; int32_t root4; bool has_normals, degenerate; };
     std::vector<MeshDev> md(fs->n_meshes);
     std::vector<DNode4> all_nodes4;
     std::vector<DTri> all_tris;
@@ -617,6 +620,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         md[mi].tri_base = (uint32_t)all_tris.size();
         md[mi].n_tris = nt;
         md[mi].has_normals = m.n_normals > 0 && m.n_normal_faces > 0;
+        md[mi].degenerate = false;
         {
             int pending = 0;
             md[mi].node_base4 = (uint32_t)all_nodes4.size();
@@ -631,6 +635,14 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
             s->h_slot_face.push_back(f);
             const uint32_t* ix = m.indices + 3 * (size_t)f;
             const float *a = m.positions + 3 * (size_t)ix[0], *b = m.positions + 3 * (size_t)ix[1], *c = m.positions + 3 * (size_t)ix[2];
+            {   // Mesh::get_uv divides by the triangle's area (src/shape/mesh.rs:127-143): a zero (or non-finite) area makes the uv of ANY point
+                // on that face non-finite.  Judged in double with a generous margin: a false positive only costs shadow rays that a
+                // zero light term would have skipped (k_shade, want_shadow)
+                const double u[3] = {(double)a[0] - b[0], (double)a[1] - b[1], (double)a[2] - b[2]}, v[3] = {(double)a[0] - c[0], (double)a[1] - c[1], (double)a[2] - c[2]};
+                const double cx = u[1] * v[2] - u[2] * v[1], cy = u[2] * v[0] - u[0] * v[2], cz = u[0] * v[1] - u[1] * v[0];
+                const double area2 = cx * cx + cy * cy + cz * cz, scale2 = (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]) * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                if (!(area2 > 1e-10 * scale2) || !(area2 > 1e-24) || !std::isfinite(area2)) md[mi].degenerate = true;
+            }
             DTri t;
             float fbits; memcpy(&fbits, &f, 4);
             t.v0 = make_float4(a[0], a[1], a[2], fbits);
@@ -683,12 +695,12 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         d.id = it.id;
         d.material = it.material;
         ItemHost& ih = s->item_host[i];
-        ih = ItemHost{it.kind, it.material, it.material_cache, it.visible != 0, it.flip_normals != 0, false};
+        ih = ItemHost{it.kind, it.material, it.material_cache, it.visible != 0, it.flip_normals != 0, false, false};
         if (it.kind != RR_ITEM_SPHERE) {
             const MeshDev& m = md[it.mesh];
             d.tri_base = m.tri_base; d.n_tris = m.n_tris;
             d.node_base4 = m.node_base4; d.root4 = m.root4;
-            ih.mesh_has_normals = m.has_normals;
+            ih.mesh_has_normals = m.has_normals; ih.mesh_degenerate = m.degenerate;
         }
         const uint32_t f = item_flags(ih, cache, full, s->tex_width);
         d.flags = f;

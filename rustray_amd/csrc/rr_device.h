@@ -65,6 +65,8 @@ enum : uint32_t {
     RR_IF_SPHERE = 1u << 7,
     RR_IF_OCCLUDER_ALPHA_TEX = 1u << 8, // full material has an alpha texture (shadow attenuation lookup)
     RR_IF_HAS_UV_FACES = 1u << 9,
+    RR_IF_UV_MAY_BE_NAN = 1u << 10, // get_uv of this item can return a non-finite value for a finite point: every sphere (acos beyond 1 away
+                                    // from its surface), a mesh with a zero-area triangle (area weights 0/0).  k_shade, want_shadow.
 };
 
 // 208 B instance record.  Rows of the column-major matrices, so that
@@ -123,7 +125,7 @@ struct DSceneView {
     const DNode4* tnodes4;  // the top level over item world boxes, same form (one item per leaf)
     int32_t tlas_root4;      // node index, a leaf code (one item), or RR_SENTINEL (empty scene)
     const float4* item_boxes; // the same padded world boxes per item: [2 i] = lo, [2 i + 1] = hi (the packet form of the top level, trace_closest_packet)
-    uint32_t any_alpha_occluder; // some item's material has an alpha map: its shadow attenuation can be NaN (k_shade, want_shadow)
+    uint32_t any_alpha_occluder; // some item's material has an alpha map: the shadow attenuation of a receiver whose uv may be NaN can be NaN (k_shade, want_shadow)
     uint32_t general_w;      // some trans_inv has a w row other than (0,0,0,1)
     uint32_t compat;         // RR_COMPAT_* (rr_scene_set_compat): behaviours of earlier reference binaries; 0 = the source at HEAD
 };

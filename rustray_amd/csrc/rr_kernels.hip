@@ -1601,10 +1601,12 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
             const float cb = ((L.color[2] * (specular_color.z * light_power + base_color.z * dot_light)) * intensity) * w_light;
             const bool nonzero = (cr != 0.0f) || (cg != 0.0f) || (cb != 0.0f);
             // A light term that is exactly zero stays zero whatever the shadow query says, so its ray is not traced -- unless
-            // an occluder with an alpha map exists: the reference samples that map at the RECEIVER's uv of the OCCLUDER's
-            // hit point (:905), which for a sphere receiver can be acos of a value beyond 1 = NaN, and 0 * NaN = NaN reaches
-            // the pixel (found by tools/fuzz_parity.py: a white pixel in the reference, a dark one here).
-            const bool want_shadow = (m.flags & RR_MF_RECEIVE_SHADOW) != 0u && (nonzero || sc.any_alpha_occluder != 0u);
+            // an occluder with an alpha map exists AND this receiver's uv can be non-finite: the reference samples that map at the
+            // RECEIVER's uv of the OCCLUDER's hit point (:905), which for a sphere receiver is acos of a value beyond 1 = NaN (for
+            // a mesh receiver: the 0 / 0 area weights of a zero-area face), and 0 * NaN = NaN reaches the pixel (found by
+            // tools/fuzz_parity.py: a white pixel in the reference, a dark one here).  Every other receiver's uv is finite, the
+            // attenuation is finite, and zero stays zero: a scene with alpha-mapped foliage does not pay for the corner case.
+            const bool want_shadow = (m.flags & RR_MF_RECEIVE_SHADOW) != 0u && (nonzero || (sc.any_alpha_occluder != 0u && (it_flags & RR_IF_UV_MAY_BE_NAN) != 0u));
             if (!(m.flags & RR_MF_RECEIVE_SHADOW) && nonzero) {
                 nf |= nonfinite_flags(cr, cg, cb);
                 fix_add(sum_r, cr, RR_FIX_SCALE, RR_FIX_CLAMP, acc.rgb, pix); fix_add(sum_g, cg, RR_FIX_SCALE, RR_FIX_CLAMP, acc.rgb + acc.n, pix);

@@ -166,3 +166,53 @@ def test_non_finite_samples_reach_the_pixel_as_in_the_reference(hip, oracle, nam
     res = compare_frames(out, ref)
     assert res["n_rgb_over"] == 0 and res["n_id_diff"] == 0 and res["nan_mismatch"] == 0, res
     assert int((ref["rgba"][..., :3] == 255).all(axis=-1).sum()) >= 1   # the white pixels are there
+
+
+def test_zero_light_term_still_reaches_the_pixel_through_a_nan_uv_and_only_then(hip, oracle):
+    """A light term that is exactly zero (light behind the receiver, no specular colour) is NaN in the reference when the occluder
+    has an alpha map and the RECEIVER's get_uv of the occluder's hit point is not finite (src/raytracing.rs:898-912: 0 * NaN): the pixel
+    turns white.  Receivers whose uv can be non-finite: every sphere, and a mesh with a zero-area face (0 / 0 area weights,
+    src/shape/mesh.rs:127-143) -- the occluder's face id picks the receiver's face.  For every other receiver the zero term stays zero,
+    and the device does not trace its shadow ray at all (D7): same frame, fewer shadow rays than the reference traces."""
+    rng = np.random.default_rng(9)
+    alpha = np.zeros((8, 8, 4), np.uint8); alpha[..., :3] = rng.integers(40, 255, (8, 8, 1)).astype(np.uint8); alpha[..., 3] = 255
+
+    def scene(degenerate):
+        fs = FlatScene()
+        fs.textures = [alpha]
+        floor = _quad(0.0, 6.0)
+        # a third face: degenerate (three collinear vertices) or a proper sliver beside the quad
+        third = [[7.0, 0.0, 0.0], [8.0, 0.0, 0.0], [9.0, 0.0, 0.0]] if degenerate else [[7.0, 0.0, 0.0], [8.0, 0.0, 0.0], [8.0, 0.0, -1.0]]
+        floor.positions = np.concatenate([floor.positions, np.asarray(third, np.float32)])
+        floor.indices = np.concatenate([floor.indices, np.asarray([[4, 5, 6]], np.uint32)])
+        floor.uvs = np.concatenate([floor.uvs, np.asarray([[0.2, 0.2], [0.8, 0.3], [0.5, 0.9]], np.float32)])
+        floor.uv_indices = np.concatenate([floor.uv_indices, np.asarray([[4, 5, 6]], np.uint32)])
+        # the occluder BELOW the floor, three faces so that face id 2 exists: the receiver's face 2 is the third one
+        p = np.asarray([[-4, -2, 4], [4, -2, 4], [4, -2, -4], [-4, -2, -4], [0, -2, 0]], np.float32)
+        cover = MeshData(positions=p, indices=np.asarray([[0, 1, 4], [1, 2, 4], [2, 3, 0]], np.uint32),
+                         uvs=np.asarray([[0, 0], [1, 0], [1, 1], [0, 1], [0.5, 0.5]], np.float32), uv_indices=np.asarray([[0, 1, 4], [1, 2, 4], [2, 3, 0]], np.uint32))
+        fs.meshes = [floor, cover]
+        fm = Material(base_color=(0.6, 0.6, 0.6), specular_color=(0.0, 0.0, 0.0), ambient_color=(0.2, 0.1, 0.05), cast_shadow=False)
+        _mesh_item(fs, 0, fm, 3, "floor")
+        cm = Material(base_color=(0.3, 0.3, 0.9)); cm.texture[4] = 0     # alpha map, bilinear (the default filter)
+        _mesh_item(fs, 1, cm, 6, "cover")
+        fs.lights = [Light(pos=(0.5, -9.0, -0.5), intensity=60.0)]        # BELOW the floor: dot(normal, to_light) < 0, the term is exactly zero
+        _cam(fs)
+        return fs
+
+    white = {}
+    for degenerate in (True, False):
+        fs = scene(degenerate)
+        cam = camera_for(fs, 96, 96).c_struct()
+        cfg = make_config(samples=2, monte_carlo=False, seed=3)
+        with hip.DeviceScene(fs, 0) as ds:
+            out = ds.render(cam, cfg)
+            st = ds.stats()
+        ref = oracle.render(fs.c_struct(), cam, cfg, n_threads=8, want_counters=True)
+        assert_parity(out, ref)
+        white[degenerate] = int((out["rgba"][..., :3] == 255).all(axis=-1).sum())
+        if degenerate:
+            assert st["shadow_rays"] > 0                                   # traced although every term is zero: the NaN has to be found
+        else:
+            assert st["shadow_rays"] == 0 and ref["counters"]["rays_shadow"] > 0   # (D7) nothing to find: not traced
+    assert white[True] > 50 and white[False] == 0, white

@@ -4,7 +4,7 @@
     <name>_hbm_traffic.json           FETCH_SIZE / WRITE_SIZE per kernel (separate passes, gfx950 correction applied)
     <name>_sq_counters.json           SQ instruction / wait counters per kernel + the derived issue fractions bench.py quotes
     <name>_tcp_counters.json          vector-L1 (TCP) and L2 (TCC) counters per kernel
-usage: python tools/summarize_profiles.py <tag> <name>   e.g. r02c r02"""
+usage: python tools/summarize_profiles.py <tag> <name> [build note]   e.g. r02c r02"""
 import collections
 import csv
 import glob
@@ -112,6 +112,9 @@ if sq:
            "workload": workload + ", one frame; counters summed over the launches of the frame",
            "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_INSTS_* count wave-instructions; SQ_BUSY_CYCLES is summed over the shader engines",
            "valu_issue_peak": f"{N_SIMD} SIMD-32 x {CLOCK_GHZ} GHz / 2 cycles per wave64 VALU instruction = {N_SIMD * CLOCK_GHZ / 2:.1f} G wave-inst/s",
+           "source_id": (bench or {}).get("source_id"),   # rustray_amd.capi.source_id() of the build that was profiled: bench.py quotes valu_insts_per_ray only for the same sources
+           "build_note": sys.argv[3] if len(sys.argv) > 3 else "the shipped build (rustray_amd/csrc/Makefile flags)",
+           "frame_checksum": (bench or {}).get("frame_checksum"),
            "kernels": {}}
     for k in KERNELS:
         if k not in sq:
