@@ -268,7 +268,8 @@ typedef struct rr_tuning {
     uint64_t queue_budget_bytes; /* ray-arena memory: 0 = a quarter of the free HBM, at most 64 GB */
     uint64_t shade_chunk_rays;   /* rays shaded per launch: 0 = 64 Mi (minimum 65536) */
     uint32_t kernel_timing;      /* non-zero: per-launch HIP events fill the ms_* fields of rr_frame_stats */
-    uint32_t _pad;
+    uint32_t multi_force_staged; /* rr_render_multi, read from scenes[0]: non-zero stages every device's buffers through pinned host memory even
+                                    where peer access exists (the path taken between devices WITHOUT peer access; lets one GPU exercise it) */
     uint64_t bin_min_rays;       /* deeper depth levels of at least this many rays are re-ordered by (origin cell, direction
                                     octant) before they are traced: 0 = never (measured: spawn order is already coherent) */
 } rr_tuning;

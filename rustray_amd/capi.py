@@ -223,11 +223,11 @@ class DeviceScene:
         _check(lib().rr_scene_update_materials(self._h, arr, len(materials)))
 
     def set_tuning(self, **kw):
-        """rr_scene_set_tuning: sample_group, queue_budget_bytes, shade_chunk_rays, kernel_timing, bin_min_rays (others keep their value)."""
+        """rr_scene_set_tuning: sample_group, queue_budget_bytes, shade_chunk_rays, kernel_timing, multi_force_staged, bin_min_rays (others keep their value)."""
         t = rr_tuning()
         _check(lib().rr_scene_get_tuning(self._h, C.byref(t)))
         for k, v in kw.items():
-            if k not in ("sample_group", "queue_budget_bytes", "shade_chunk_rays", "kernel_timing", "bin_min_rays"):
+            if k not in ("sample_group", "queue_budget_bytes", "shade_chunk_rays", "kernel_timing", "multi_force_staged", "bin_min_rays"):
                 raise TypeError(f"unknown tuning field {k}")
             setattr(t, k, int(v) & 0xffffffffffffffff)
         t.struct_size = C.sizeof(rr_tuning)

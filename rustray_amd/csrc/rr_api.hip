@@ -89,6 +89,7 @@ struct rr_scene {
     std::vector<uint32_t> h_slot_face; // per mesh triangle: leaf-order slot -> original face index (rr_trace_rays reports the reference's face id)
     std::vector<ItemHost> item_host; // what rr_scene_update_materials needs to rebuild the item flag words
     std::vector<uint32_t> tex_width;
+    std::vector<DTexture> h_textures; // descriptors of the uploaded images (copied into the material records, make_dmaterial)
     uint32_t n_materials = 0;
     uint32_t n_enabled_lights = 0;
     uint32_t tlas_node_capacity = 0;
@@ -329,7 +330,7 @@ static int validate_scene(const rr_flat_scene* fs) {
 }
 
 // Material (reference src/shape/mod.rs:95-134) -> device record; has_texture = the slot names an image of width > 0
-static DMaterial make_dmaterial(const rr_material& m, const std::vector<uint32_t>& tex_width) {
+static DMaterial make_dmaterial(const rr_material& m, const std::vector<uint32_t>& tex_width, const std::vector<DTexture>& dtex) {
     DMaterial d;
     memset(&d, 0, sizeof d);
     for (int k = 0; k < 3; k++) { d.ambient[k] = m.ambient_color[k]; d.base[k] = m.base_color[k]; d.specular[k] = m.specular_color[k]; }
@@ -340,6 +341,7 @@ static DMaterial make_dmaterial(const rr_material& m, const std::vector<uint32_t
     uint32_t slots = 0u;
     for (int k = 0; k < RR_TEX_COUNT; k++) {
         d.tex[k] = m.texture[k];
+        if (m.texture[k] >= 0) { const DTexture& t = dtex[m.texture[k]]; d.texd[k].offset = t.offset; d.texd[k].width = t.width; d.texd[k].height = t.height; }
         if (m.texture[k] >= 0 && tex_width[m.texture[k]] > 0) { any = true; slots |= RR_MF_TEX_SLOT0 << k; }
     }
     d.flags = slots | (m.texture_filtering_nearest ? RR_MF_NEAREST : 0u) | (m.receive_shadow ? RR_MF_RECEIVE_SHADOW : 0u) |
@@ -551,7 +553,8 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     s->tex_width.resize(fs->n_textures);
     for (uint32_t i = 0; i < fs->n_textures; i++) s->tex_width[i] = fs->textures[i].width;
     std::vector<DMaterial> dmat(fs->n_materials);
-    for (uint32_t i = 0; i < fs->n_materials; i++) dmat[i] = make_dmaterial(fs->materials[i], s->tex_width);
+    s->h_textures = dtex;
+    for (uint32_t i = 0; i < fs->n_materials; i++) dmat[i] = make_dmaterial(fs->materials[i], s->tex_width, s->h_textures);
     HIP_TRY(s->materials.reserve(std::max<size_t>(dmat.size(), 1) * sizeof(DMaterial)));
     if (!dmat.empty()) HIP_TRY(hipMemcpy(s->materials.p, dmat.data(), dmat.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
 
@@ -732,7 +735,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     HIP_TRY(upload(s->item_boxes, s->h_item_boxes.data(), s->h_item_boxes.size() * sizeof(float4)));
     HIP_TRY(upload(s->tris, all_tris.data(), all_tris.size() * sizeof(DTri)));
     if (all_trix.size() >= (1u << 26)) return fail(RR_ERR_UNSUPPORTED, "%zu triangles (addressed with 32-bit byte offsets)", all_trix.size());
-    static_assert(sizeof(DTriX) == 48 && sizeof(DNode4) == 128 && sizeof(DMaterial) == 112, "layouts the kernels address by byte offset");
+    static_assert(sizeof(DTriX) == 48 && sizeof(DNode4) == 128 && sizeof(DMaterial) == 240, "layouts the kernels address by byte offset");
     HIP_TRY(upload(s->trix, all_trix.data(), all_trix.size() * sizeof(DTriX)));
     HIP_TRY(upload(s->attrs, all_attrs.data(), all_attrs.size() * sizeof(DTriAttr)));
     HIP_TRY(upload(s->face_slot, all_face_slot.data(), all_face_slot.size() * 4));
@@ -810,7 +813,7 @@ extern "C" int rr_scene_update_materials(rr_scene* s, const rr_material* materia
                 return fail(RR_ERR_INVALID_ARGUMENT, "material %d is a material cache and must not carry textures (reference src/shape/mod.rs:769-772)", ih.material_cache);
     HIP_TRY(hipSetDevice(s->device));
     std::vector<DMaterial> dmat(n_materials);
-    for (uint32_t i = 0; i < n_materials; i++) dmat[i] = make_dmaterial(materials[i], s->tex_width);
+    for (uint32_t i = 0; i < n_materials; i++) dmat[i] = make_dmaterial(materials[i], s->tex_width, s->h_textures);
     s->view.any_alpha_occluder = 0u;
     for (size_t i = 0; i < s->item_host.size(); i++) {
         s->h_items[i].flags = item_flags(s->item_host[i], materials[s->item_host[i].material_cache], materials[s->item_host[i].material], s->tex_width);
@@ -1427,7 +1430,7 @@ extern "C" int rr_render_multi(rr_scene* const* scenes, uint32_t n_scenes, const
     std::vector<char> direct(n_scenes, 1);
     uint32_t n_peer = 0, n_staged = 0;
     for (uint32_t i = 1; i < n_scenes; i++) {
-        direct[i] = ensure_peer_access(scenes[i]->device, s0->device) ? 1 : 0;
+        direct[i] = (s0->tuning.multi_force_staged == 0u && ensure_peer_access(scenes[i]->device, s0->device)) ? 1 : 0;
         if (direct[i]) n_peer++; else n_staged++;
     }
     auto own_stream = [](rr_scene* s) -> int { // on the scene's device
@@ -1462,7 +1465,7 @@ extern "C" int rr_render_multi(rr_scene* const* scenes, uint32_t n_scenes, const
                     if (!host[k] || !count[i]) continue;
                     const size_t bytes = count[i] * esz[k];
                     void* dst = (char*)s0->multi_cat[k].p + offset[i] * esz[k];
-                    if (s->device == s0->device) HIP_TRY(hipMemcpyAsync(dst, s->multi_part[k].p, bytes, hipMemcpyDeviceToDevice, s->multi_stream));
+                    if (direct[i] && s->device == s0->device) HIP_TRY(hipMemcpyAsync(dst, s->multi_part[k].p, bytes, hipMemcpyDeviceToDevice, s->multi_stream));
                     else if (direct[i]) HIP_TRY(hipMemcpyPeerAsync(dst, s0->device, s->multi_part[k].p, s->device, bytes, s->multi_stream));
                     else { // no peer access: device -> pinned host here, host -> device 0 after the join
                         if (s->multi_stage_bytes[k] < bytes) {

@@ -85,7 +85,7 @@ struct DItem {
     int32_t root4;       // node index relative to node_base4, a leaf code, or RR_SENTINEL (no triangles)
 };
 
-// 112 B material record (seven 16-B groups)
+// 240 B material record (seven 16-B groups + eight 16-B texture descriptors)
 struct DMaterial {
     float ambient[3]; float alpha;
     float base[3]; float shininess;
@@ -97,6 +97,9 @@ struct DMaterial {
     // kernels' own rr_cos (src/raytracing.rs:590-596 computes it per call; a roughness MAP gives a per-hit spread and is evaluated per hit)
     float cos_shadow_softness, cos_roughness;
     uint32_t _pad;
+    // the descriptors of the eight texture slots, copied from DSceneView::textures: a texel fetch is then material -> texel instead of
+    // material -> texture index -> descriptor -> texel (two dependent round trips fewer per fetch in k_shade's chain)
+    struct { uint64_t offset; uint32_t width, height; } texd[8];
 };
 enum : uint32_t { RR_MF_NEAREST = 1u, RR_MF_RECEIVE_SHADOW = 2u, RR_MF_MONTE_CARLO = 4u, RR_MF_ANY_TEX = 8u, RR_MF_TEX_SLOT0 = 256u };
 

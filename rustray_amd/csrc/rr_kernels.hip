@@ -934,7 +934,8 @@ RR_DEV MatR load_material(const DMaterial* p, const float* lut) {
 }
 RR_DEV bool tex_color(const DSceneView& sc, const MatR& m, bool has_uv, f2 uv, int slot, float4* out) {
     if (!(m.flags & (RR_MF_TEX_SLOT0 << slot)) || !has_uv) return false; // slot bit = index >= 0 and width > 0
-    const DTexture t = rr_global(sc.textures)[m.p->tex[slot]];
+    DTexture t; // the slot's descriptor sits in the material record itself (DMaterial::texd): one 16-B load at an address known since the material was
+    { const uint4 q = *(const uint4*)&m.p->texd[slot]; t.offset = (uint64_t)q.x | ((uint64_t)q.y << 32); t.width = q.z; t.height = q.w; }
     if (m.flags & RR_MF_NEAREST) *out = texel(sc, t, tex_wrap(uv.x, t.width), tex_wrap(uv.y, t.height), m.lut);
     else *out = tex_bilinear(sc, t, uv.x, uv.y, m.lut);
     return true;
@@ -943,7 +944,7 @@ RR_DEV bool tex_color(const DSceneView& sc, const MatR& m, bool has_uv, f2 uv, i
 RR_DEV bool tex_color(const DSceneView& sc, const DMaterial& m, bool has_uv, f2 uv, int slot, float4* out) {
     int ti = m.tex[slot];
     if (ti < 0 || !has_uv) return false;
-    const DTexture t = rr_global(sc.textures)[ti];
+    DTexture t; t.offset = m.texd[slot].offset; t.width = m.texd[slot].width; t.height = m.texd[slot].height;
     if (t.width == 0u) return false;
     if (m.flags & RR_MF_NEAREST) *out = texel(sc, t, tex_wrap(uv.x, t.width), tex_wrap(uv.y, t.height));
     else *out = tex_bilinear(sc, t, uv.x, uv.y);

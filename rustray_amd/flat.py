@@ -122,7 +122,7 @@ class rr_frame_stats(C.Structure):
 
 class rr_tuning(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("sample_group", C.c_uint32), ("queue_budget_bytes", C.c_uint64),
-                ("shade_chunk_rays", C.c_uint64), ("kernel_timing", C.c_uint32), ("_pad", C.c_uint32), ("bin_min_rays", C.c_uint64)]
+                ("shade_chunk_rays", C.c_uint64), ("kernel_timing", C.c_uint32), ("multi_force_staged", C.c_uint32), ("bin_min_rays", C.c_uint64)]
 
 
 # ---------------------------------------------------------------------------

@@ -61,6 +61,13 @@ def test_multi_reports_how_the_buffers_travelled_and_concurrent_callers_do_not_d
         assert st["ms_multi_exchange"] > 0.0
         scenes[0].render(cam, cfg)
         assert scenes[0].stats()["multi_devices"] == 0   # a single-handle frame resets it
+        # the path between devices WITHOUT peer access (device -> pinned host -> device 0), forced here where one GPU has to play both
+        scenes[0].set_tuning(multi_force_staged=1)
+        staged = hip.render_multi(scenes, cam, cfg)
+        st = scenes[0].stats()
+        assert st["multi_peer_links"] == 0 and st["multi_staged_links"] == 2
+        _same(staged, ref)
+        scenes[0].set_tuning(multi_force_staged=0)
         results, errors = {}, []
 
         def run(tag, order):
