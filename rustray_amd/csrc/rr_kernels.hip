@@ -522,6 +522,130 @@ RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, flo
 }
 
 // ---------------------------------------------------------------------------
+// The per-mesh walk of a PACKET: all 64 lanes walk ONE mesh with ONE wave-uniform control flow (trace_closest_packet /
+// trace_shadow_packet visit a candidate item with every lane together).  A node step costs its instructions per WAVE, not per
+// lane, and in a packet of 64 samples of one pixel three quarters of the per-lane steps had the same node in every lane anyway:
+// here the node index, the stack (one LDS word per entry, the wave's own column) and the order in which children are tried are
+// scalar; each lane still tests the four child boxes with ITS ray and its own bound, and tests a leaf's triangles only if ITS
+// box test of that leaf passed -- so a lane's set of tested triangles is what its own walk would test, up to nodes that a bound
+// (its best hit so far) prunes, which never changes a result: the frame is the same bit for bit.  What goes away per step is the
+// per-lane bookkeeping: the five-exchange sorting network, three LDS pushes with their addresses, the parked-leaf ballots.
+// Leaves are tested when their parent is visited (under the lanes' hit flags of that step); only inner nodes are stacked, in
+// the order of the FIRST hitting lane's entry distances (any order is correct; near-first prunes best).
+// (A bound prunes by the ORDER in which hits are found, and the order here follows the first hitting lane.  That never matters for
+// a triangle hit that lies inside its leaf's box; the per-lane walks have the same dependence on their wave through the moment at
+// which parked leaves are tested.  Where a reported toi lies in front of the leaf's box -- rounding noise for origins >~ 1e4 mesh
+// sizes away, DESIGN.md D12 -- neither form promises the reference's pick.)
+// `in`: this lane takes part (its exact test of the item's box passed).  Must be called by all 64 lanes.
+// ---------------------------------------------------------------------------
+#define RR_PK_STK(sp_) s_stack[(sp_) * RR_BLOCK + wave_col_]
+// the triangles of a wave-uniform leaf for the lanes with `hit_`, two per wait through the scalar cache
+#define RR_PK_LEAF(code_, hit_, TEST)                                                                          \
+    {                                                                                                          \
+        const uint32_t ucode = (uint32_t)~(code_);                                                             \
+        const uint32_t ufirst = RR_LEAF_FIRST(ucode), ucount = RR_LEAF_COUNT(ucode);                           \
+        const uint32_t ubase = utri_ + ufirst;                                                                 \
+        for (uint32_t i = 0; i < ucount; i += 2u) {                                                            \
+            const bool two_ = i + 1u < ucount;                                                                 \
+            const uint32_t o0 = (ubase + i) * 48u, o1 = (ubase + i + (two_ ? 1u : 0u)) * 48u;                  \
+            DTriX ta, tb;                                                                                      \
+            RR_TRI_FETCH(ta, o0) RR_TRI_FETCH(tb, o1)                                                          \
+            if (hit_) { TEST(ta, ufirst + i) if (two_) TEST(tb, ufirst + i + 1u) }                             \
+        }                                                                                                      \
+    }
+#define RR_TRI_ANY(tr, slot_)                                                                                   \
+            {                                                                                                  \
+                float t; uint32_t side;                                                                        \
+                if (ray_triangle(mk3(tr.t0.x, tr.t0.y, tr.t0.z), mk3(tr.t1.x, tr.t1.y, tr.t1.z),               \
+                                 mk3(tr.t1.w, tr.t2.x, tr.t2.y), ray, &t, &side)) {                            \
+                    any = true;                                                                                \
+                    if (t <= limit) within = true;                                                             \
+                }                                                                                              \
+            }
+// one uniform node: tests, leaves, and the choice of the next node.  BOUND: the lane's pruning bound; TEST: the triangle macro;
+// LIVE: the lane still wants hits (any-hit walks drop a lane once it is decided)
+#define RR_PK_NODE(BOUND, TEST, LIVE)                                                                          \
+    {                                                                                                          \
+        const int ucur_ = cur;                                                                                 \
+        RR_NODE4_ROWS_UNIFORM(nodes, sr)                                                                       \
+        bool h0 = false, h1 = false, h2 = false, h3 = false;                                                   \
+        float k0 = 0.0f, k1 = 0.0f, k2 = 0.0f, k3 = 0.0f;                                                      \
+        if (LIVE) {                                                                                            \
+            const float bound_ = (BOUND);                                                                      \
+            const float inf_ = __builtin_inff();                                                               \
+            RR_ROW(rnx, sr.o.x, sr.inv.x, nx01, nx23) RR_ROW(rfx, sr.o.x, sr.inv.x, fx01, fx23)                \
+            RR_ROW(rny, sr.o.y, sr.inv.y, ny01, ny23) RR_ROW(rfy, sr.o.y, sr.inv.y, fy01, fy23)                \
+            RR_ROW(rnz, sr.o.z, sr.inv.z, nz01, nz23) RR_ROW(rfz, sr.o.z, sr.inv.z, fz01, fz23)                \
+            RR_CHILD(kk0, hh0, nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x)                                 \
+            RR_CHILD(kk1, hh1, nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y)                                 \
+            RR_CHILD(kk2, hh2, nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x)                                 \
+            RR_CHILD(kk3, hh3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y)                                 \
+            h0 = hh0; h1 = hh1; h2 = hh2; h3 = hh3; k0 = kk0; k1 = kk1; k2 = kk2; k3 = kk3;                    \
+        }                                                                                                      \
+        const int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w); \
+        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);   \
+        /* leaves of this node: tested now, by the lanes that hit them */                                      \
+        if (m0 != 0ull && c0 < 0) RR_PK_LEAF(c0, h0, TEST)                                                     \
+        if (m1 != 0ull && c1 < 0) RR_PK_LEAF(c1, h1, TEST)                                                     \
+        if (m2 != 0ull && c2 < 0) RR_PK_LEAF(c2, h2, TEST)                                                     \
+        if (m3 != 0ull && c3 < 0) RR_PK_LEAF(c3, h3, TEST)                                                     \
+        /* inner children: keyed by the entry distance of the first lane that hits them (non-negative floats order as integers) */ \
+        uint32_t q0 = 0xffffffffu, q1 = 0xffffffffu, q2 = 0xffffffffu, q3 = 0xffffffffu;                       \
+        if (m0 != 0ull && c0 >= 0) q0 = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(k0), __ffsll((long long)m0) - 1); \
+        if (m1 != 0ull && c1 >= 0) q1 = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(k1), __ffsll((long long)m1) - 1); \
+        if (m2 != 0ull && c2 >= 0) q2 = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(k2), __ffsll((long long)m2) - 1); \
+        if (m3 != 0ull && c3 >= 0) q3 = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(k3), __ffsll((long long)m3) - 1); \
+        int e0 = c0, e1 = c1, e2 = c2, e3 = c3;                                                                \
+        /* scalar five-exchange network on (key, child) */                                                     \
+        RR_SCSWAP(q0, e0, q1, e1) RR_SCSWAP(q2, e2, q3, e3) RR_SCSWAP(q0, e0, q2, e2) RR_SCSWAP(q1, e1, q3, e3) RR_SCSWAP(q1, e1, q2, e2) \
+        if (q3 != 0xffffffffu) { if (lane_ == 0u) RR_PK_STK(sp) = e3; sp++; }                                   \
+        if (q2 != 0xffffffffu) { if (lane_ == 0u) RR_PK_STK(sp) = e2; sp++; }                                   \
+        if (q1 != 0xffffffffu) { if (lane_ == 0u) RR_PK_STK(sp) = e1; sp++; }                                   \
+        if (q0 != 0xffffffffu) cur = e0;                                                                       \
+        else if (sp > sp_base) { sp--; __builtin_amdgcn_wave_barrier(); cur = __builtin_amdgcn_readfirstlane(RR_PK_STK(sp)); } \
+        else cur = RR_SENTINEL;                                                                                \
+    }
+#define RR_SCSWAP(ka, ca, kb, cb) { const bool s_ = kb < ka; const uint32_t tk_ = s_ ? ka : kb; const int tc_ = s_ ? ca : cb; \
+                                    ka = s_ ? kb : ka; ca = s_ ? cb : ca; kb = tk_; cb = tc_; }
+
+// returns false (nothing done) when the lanes do not share their direction signs in the mesh's space: the caller walks per lane
+RR_DEV bool blas_closest_packet(const DSceneView& sc, const DItem& it, const LRay& ray, bool in, float gbound,
+                                int* s_stack, int sp_base, TriBest* out) {
+    const BlasSlab sr = RR_BLAS_SLAB(ray);
+    if (!sr.uni) return false;
+    TriBest best; best.found = false; best.t = RR_FLT_MAX; best.slot = 0; best.face = 0xffffffffu; best.side = 0u;
+    const BlasNode* nodes = RR_BLAS_NODES(sc, it);
+    const uint32_t utri_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.tri_base);
+    const uint32_t wave_col_ = threadIdx.x & ~(RR_WAVE - 1u), lane_ = threadIdx.x & (RR_WAVE - 1u);
+    int sp = sp_base;
+    int cur = __builtin_amdgcn_readfirstlane(RR_BLAS_ROOT(it));
+    if (cur < 0 && cur != RR_SENTINEL) { RR_PK_LEAF(cur, in, RR_TRI_CLOSEST) cur = RR_SENTINEL; } // a mesh of one leaf
+    while (cur >= 0) RR_PK_NODE(fminf(gbound, best.t), RR_TRI_CLOSEST, in)
+    *out = best;
+    return true;
+}
+RR_DEV bool blas_any_packet(const DSceneView& sc, const DItem& it, const LRay& ray, bool in, float limit,
+                            int* s_stack, int sp_base, bool* found_any, bool* found_within) {
+    const BlasSlab sr = RR_BLAS_SLAB(ray);
+    if (!sr.uni) return false;
+    bool any = false, within = false;
+    const BlasNode* nodes = RR_BLAS_NODES(sc, it);
+    const uint32_t utri_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.tri_base);
+    const uint32_t wave_col_ = threadIdx.x & ~(RR_WAVE - 1u), lane_ = threadIdx.x & (RR_WAVE - 1u);
+    int sp = sp_base;
+    int cur = __builtin_amdgcn_readfirstlane(RR_BLAS_ROOT(it));
+    if (cur < 0 && cur != RR_SENTINEL) { RR_PK_LEAF(cur, in, RR_TRI_ANY) cur = RR_SENTINEL; }
+    // a lane is decided once it has a hit within the limit; until some hit is known every box matters, afterwards only boxes
+    // that can still hold a hit within the limit (as in blas_any); the walk ends when no lane is left
+    while (cur >= 0) {
+        RR_PK_NODE(any ? limit : RR_FLT_MAX, RR_TRI_ANY, in && !within)
+        if (__ballot(in && !within) == 0ull) break;
+    }
+    *found_any = any; *found_within = within;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
 // Raytracing::trace (reference src/raytracing.rs:429-490) per item
 // ---------------------------------------------------------------------------
 // Aabb::cast_local_ray with the entry distance kept beside the returned toi: origin inside a
@@ -591,6 +715,36 @@ RR_DEV void closest_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t dep
                   (t == best->t && (key < best->key || (key == best->key && idx < best->item)));
     if (better) { best->found = true; best->t = t; best->item = idx; best->face = face; best->key = key; }
 }
+
+// closest_item for a candidate that ALL lanes of a packet visit together (trace_closest_packet): a mesh is walked once per wave
+// (blas_closest_packet), with the lanes whose exact box test passed taking part.  Same result as closest_item, lane by lane.
+#ifndef RR_NO_PACKET_WALK
+RR_DEV void closest_item_packet(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t depth, int* s_stack, Closest* best) {
+    const DItem& it = rr_global(sc.items)[idx];
+    const uint32_t flags = it.flags;
+    if (flags & RR_IF_SPHERE) { closest_item(sc, idx, o, d, depth, s_stack, 0, best); return; } // (wave-uniform: one item)
+    RR_UTIL(1)
+    bool in = item_passes(flags, false, depth) && it.n_tris != 0u;
+    const LRay lr = inverse_ray(it, o, d, sc.general_w != 0u);
+    float key = 0.0f;
+    in = in && aabb_cast(it.bmin, it.bmax, lr, (flags & RR_IF_SOLID_BASE) != 0u, &key);
+    in = in && key == key; // NaN distance: treated as a miss (the reference panics)
+    if (__ballot(in) == 0ull) return;
+    const float gbound = best->found ? best->t : RR_FLT_MAX;
+    TriBest tb; tb.found = false; tb.t = RR_FLT_MAX; tb.slot = 0u; tb.face = 0xffffffffu; tb.side = 0u;
+    if (!blas_closest_packet(sc, it, lr, in, gbound, s_stack, 0, &tb)) {
+        if (in) blas_closest<true>(sc, it, lr, gbound, s_stack, 0, &tb);
+    }
+    if (in && tb.found) {
+        const float t = tb.t;
+        const uint32_t face = tb.slot | (tb.side << 30); // bit31 back face, bit30 negated normal
+        const bool better = !best->found || t < best->t || (t == best->t && (key < best->key || (key == best->key && idx < best->item)));
+        if (better) { best->found = true; best->t = t; best->item = idx; best->face = face; best->key = key; }
+    }
+}
+#else
+RR_DEV void closest_item_packet(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t depth, int* s_stack, Closest* best) { closest_item(sc, idx, o, d, depth, s_stack, 0, best); }
+#endif
 
 RR_DEV void trace_closest_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, int* s_stack, Closest* best) {
     best->found = false; best->t = RR_FLT_MAX; best->item = -1; best->face = 0u; best->key = 0.0f;
@@ -745,7 +899,7 @@ RR_DEV bool trace_closest_packet(const DSceneView& sc, f3 o, f3 d, uint32_t dept
     while (beam_next(sk, item, &key, &idx)) {
         // the remaining boxes all start at or behind this one: done when that is behind every lane's best hit
         if (__ballot(!best->found || key <= best->t) == 0ull) break;
-        closest_item(sc, idx, o, d, depth, s_stack, 0, best);
+        closest_item_packet(sc, idx, o, d, depth, s_stack, best);
     }
     return true;
 }
@@ -784,6 +938,33 @@ RR_DEV void shadow_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t dept
     }
     if (any) { sel->found = true; sel->key = key; sel->item = idx; sel->within = within; sel->t = t; sel->face = face; }
 }
+
+// shadow_item for a candidate that all lanes of a packet visit together (trace_shadow_packet): a mesh without an alpha map is
+// walked once per wave (blas_any_packet).  Same result as shadow_item, lane by lane.  OFF by default (-DRR_PACKET_WALK_SHADOW):
+// parity-green, but any-hit lanes leave their walk one by one as they find a hit and a shared walk goes on for the rest -- level-1
+// shadow time 5.96 -> 6.02 ms on sponza_syn, where the closest-hit kernel gains 3 % from the same form.
+#ifdef RR_PACKET_WALK_SHADOW
+RR_DEV void shadow_item_packet(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t depth, float limit, int* s_stack, ShadowSel* sel) {
+    const DItem& it = rr_global(sc.items)[idx];
+    const uint32_t flags = it.flags;
+    if (flags & (RR_IF_SPHERE | RR_IF_OCCLUDER_ALPHA_TEX)) { shadow_item(sc, idx, o, d, depth, limit, s_stack, 0, sel); return; } // (wave-uniform)
+    RR_UTIL(1)
+    bool in = item_passes(flags, true, depth) && it.n_tris != 0u;
+    const LRay lr = inverse_ray(it, o, d, sc.general_w != 0u);
+    float key = 0.0f, tmin = 0.0f;
+    in = in && aabb_cast2(it.bmin, it.bmax, lr, false, &key, &tmin); // for_shadow forces solid = false
+    in = in && key == key && !(tmin > limit * RR_TOI_SLACK);
+    in = in && !(sel->found && !(key < sel->key || (key == sel->key && idx < sel->item)));
+    if (__ballot(in) == 0ull) return;
+    bool any = false, within = false;
+    if (!blas_any_packet(sc, it, lr, in, limit, s_stack, 0, &any, &within)) {
+        if (in) blas_any(sc, it, lr, limit, s_stack, 0, &any, &within);
+    }
+    if (in && any) { sel->found = true; sel->key = key; sel->item = idx; sel->within = within; sel->t = 0.0f; sel->face = 0u; }
+}
+#else
+RR_DEV void shadow_item_packet(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t depth, float limit, int* s_stack, ShadowSel* sel) { shadow_item(sc, idx, o, d, depth, limit, s_stack, 0, sel); }
+#endif
 
 // Second pass of a shadow query: is there an item whose box starts BEYOND the light (skipped above), ordered before
 // the selected occluder (sel), that is hit at all?  The reference tries candidates in bbox-distance order and the
@@ -870,7 +1051,7 @@ RR_DEV bool trace_shadow_packet(const DSceneView& sc, f3 o, f3 d, uint32_t depth
     float key; int idx;
     while (beam_next(sk, item, &key, &idx)) {
         if (__ballot(key <= RR_SHADOW_BOUND) == 0ull) break; // (a NaN light distance compares false: that lane wants nothing, as in the per-ray walk)
-        shadow_item(sc, idx, o, d, depth, limit, s_stack, 0, sel);
+        shadow_item_packet(sc, idx, o, d, depth, limit, s_stack, sel);
     }
     if (sel->found && sel->within && sel->key > limit && trace_shadow_blockers(sc, o, d, depth, limit, *sel, s_stack)) sel->within = false;
     return true;
