@@ -48,14 +48,18 @@ typedef enum rr_status {
     RR_ERR_CANCELLED = -6          /* *cancel became non-zero during the frame */
 } rr_status;
 
-/* Largest RaytracingConfig::max_recursion the device path accepts
- * (reference default is 6, src/raytracing.rs:124). */
-#define RR_MAX_RECURSION 16u
+/* Largest RaytracingConfig::max_recursion the device path accepts (reference default: 6, src/raytracing.rs:124).  A path node at
+ * recursion depth d carries d in five bits of its shadow-ray records and its index (root 1, children 2k and 2k + 1) in 32: depth
+ * max_recursion + 1 <= 31. */
+#define RR_MAX_RECURSION 30u
 
 /* Largest RaytracingConfig::samples accepted.  The reference computes the sub-sample cell size as
- * `(samples + 2).next_power_of_two() / 2` in u16 arithmetic (src/raytracing.rs:297), which overflows from
- * 32767 samples on, and shuffles cell_size^2 cells; 16382 is the last count of the cell size below that
- * (cell_size 8192: a table of 8192^2 = 67 M cells, 268 MB of host memory while it is shuffled). */
+ * `(samples + 2).next_power_of_two() / 2` in u16 arithmetic (src/raytracing.rs:297), which overflows from 32767 samples on:
+ * RR_MAX_SAMPLES_WITH_TABLE = 32766 is the reference's own limit, accepted whenever the caller passes its sub-sample table
+ * (`sample_xy`, the recommended way: INTEGRATION.md).  The BUILT-IN table (sample_xy = NULL, rr_sample_table) is limited to
+ * RR_MAX_SAMPLES = 16382, the last count of the cell size below that (cell_size 8192: 8192^2 = 67 M cells, 268 MB of host memory
+ * while they are shuffled; the next cell size needs 1 GB). */
+#define RR_MAX_SAMPLES_WITH_TABLE 32766u
 #define RR_MAX_SAMPLES 16382u
 
 /* TextureType order of reference src/shape/mod.rs:633-643. */

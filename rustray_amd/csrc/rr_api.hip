@@ -828,10 +828,13 @@ extern "C" int rr_scene_update_materials(rr_scene* s, const rr_material* materia
 // ---------------------------------------------------------------------------
 // frame
 // ---------------------------------------------------------------------------
-static int check_frame_args(const rr_scene* s, const rr_camera* cam, const rr_config* cfg) {
+static int check_frame_args(const rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy) {
     if (!s || !cam || !cfg) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
     if (cfg->samples == 0) return fail(RR_ERR_INVALID_ARGUMENT, "samples must be >= 1");
-    if (cfg->samples > RR_MAX_SAMPLES) return fail(RR_ERR_UNSUPPORTED, "samples %u > %u", (unsigned)cfg->samples, RR_MAX_SAMPLES);
+    // with the caller's table the reference's own u16 limit applies; the built-in table stops where its shuffle stays affordable
+    if (cfg->samples > (sample_xy ? RR_MAX_SAMPLES_WITH_TABLE : RR_MAX_SAMPLES))
+        return fail(RR_ERR_UNSUPPORTED, "samples %u > %u%s", (unsigned)cfg->samples, sample_xy ? RR_MAX_SAMPLES_WITH_TABLE : RR_MAX_SAMPLES,
+                    sample_xy ? "" : " (the built-in sub-sample table; pass sample_xy for up to 32766)");
     if (cfg->max_recursion > RR_MAX_RECURSION) return fail(RR_ERR_UNSUPPORTED, "max_recursion %u > %u", cfg->max_recursion, RR_MAX_RECURSION);
     if (cam->width == 0 || cam->height == 0 || cam->width > 65535u || cam->height > 65535u) return fail(RR_ERR_INVALID_ARGUMENT, "bad frame size %ux%u", cam->width, cam->height);
     if (!finite16(cam->projection_inverse) || !finite16(cam->view_inverse)) return fail(RR_ERR_INVALID_ARGUMENT, "non-finite camera matrix");
@@ -1220,7 +1223,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
 
 extern "C" int rr_render_region_device(rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy,
                                        const rr_region* rg, const rr_frame* out, void* hip_stream, const volatile int* cancel) {
-    int rc = check_frame_args(s, cam, cfg);
+    int rc = check_frame_args(s, cam, cfg, sample_xy);
     if (rc != RR_OK) return rc;
     rc = check_region(cam->width, cam->height, rg);
     if (rc != RR_OK) return rc;
@@ -1231,7 +1234,7 @@ extern "C" int rr_render_region_device(rr_scene* s, const rr_camera* cam, const 
 
 static int render_to_host(rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy, const rr_frame* out,
                           const volatile int* cancel, rr_pass_fn fn, void* user, uint32_t min_passes) {
-    int rc = check_frame_args(s, cam, cfg);
+    int rc = check_frame_args(s, cam, cfg, sample_xy);
     if (rc != RR_OK) return rc;
     if (!out || !out->rgba8) return fail(RR_ERR_INVALID_ARGUMENT, "out->rgba8 is required");
     std::lock_guard<std::mutex> lk(s->mu);
@@ -1404,7 +1407,7 @@ extern "C" int rr_render_multi(rr_scene* const* scenes, uint32_t n_scenes, const
     for (uint32_t i = 0; i < n_scenes; i++) {
         if (!scenes[i]) return fail(RR_ERR_INVALID_ARGUMENT, "scene %u is NULL", i);
         for (uint32_t j = 0; j < i; j++) if (scenes[j] == scenes[i]) return fail(RR_ERR_INVALID_ARGUMENT, "scene handle %u is passed twice", i);
-        int rc = check_frame_args(scenes[i], cam, cfg);
+        int rc = check_frame_args(scenes[i], cam, cfg, sample_xy);
         if (rc != RR_OK) return rc;
     }
     if (!out || !out->rgba8) return fail(RR_ERR_INVALID_ARGUMENT, "out->rgba8 is required");

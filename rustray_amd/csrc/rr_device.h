@@ -166,7 +166,10 @@ struct DRayQueue {
 //   s2 = (contribution rgb, bits(accumulator slot))
 // scenes whose top level has a packet form (rr_kernels.hip: beam_candidates)
 #define RR_BEAM_MAX_ITEMS 512u // 8 passes of 64 boxes: about what three steps of the per-ray walk cost
-#define RR_BEAM_MIN_ITEMS 17u  // up to 16 items the tree is two levels: the per-ray walk is cheaper than the packet's set-up
+#define RR_BEAM_MIN_ITEMS 17u  // up to 16 items the tree is two levels: the per-ray walk is cheaper than the packet's set-up (shadow rays)
+#ifndef RR_BEAM_MIN_ITEMS_CLOSEST
+#define RR_BEAM_MIN_ITEMS_CLOSEST 17u // the same bound for closest-hit packets (their packet form also walks a mesh once per wave)
+#endif
 
 struct DShadowQueue {
     float4* s0;

@@ -837,9 +837,9 @@ RR_DEV void beam_axis(bool neg, float blo, float bhi, float olo, float ohi, floa
 // The candidate list of a packet: lane l of the wave holds candidate l as (sort key, item); the key keeps the upper bits
 // of the distance at which the item's box can first be entered by any ray of the packet (a lower bound) and the lane in
 // its low six bits, 0xffffffff = none.  `far`: (wave-uniform) boxes that start beyond it are of no interest.
-RR_DEV bool beam_candidates(const DSceneView& sc, f3 o, f3 d, float far, int* s_stack, uint32_t* sk_out, int* item_out) {
+RR_DEV bool beam_candidates(const DSceneView& sc, f3 o, f3 d, float far, int* s_stack, uint32_t* sk_out, int* item_out, uint32_t min_items = RR_BEAM_MIN_ITEMS) {
     const uint32_t n_items = sc.n_items;
-    if (n_items > RR_BEAM_MAX_ITEMS || n_items < RR_BEAM_MIN_ITEMS) return false;
+    if (n_items > RR_BEAM_MAX_ITEMS || n_items < min_items) return false;
     // coherent: finite rays, no zero direction component, one sign per axis
     const bool bad = ray_nonfinite(o, d) || !(fabsf(d.x) > 1e-30f) || !(fabsf(d.y) > 1e-30f) || !(fabsf(d.z) > 1e-30f);
     const unsigned long long nx_ = __ballot(d.x < 0.0f), ny_ = __ballot(d.y < 0.0f), nz_ = __ballot(d.z < 0.0f);
@@ -893,7 +893,7 @@ RR_DEV bool beam_next(uint32_t& sk, int item, float* key, int* idx) {
 }
 RR_DEV bool trace_closest_packet(const DSceneView& sc, f3 o, f3 d, uint32_t depth, int* s_stack, Closest* best) {
     uint32_t sk; int item;
-    if (!beam_candidates(sc, o, d, RR_FLT_MAX, s_stack, &sk, &item)) return false;
+    if (!beam_candidates(sc, o, d, RR_FLT_MAX, s_stack, &sk, &item, RR_BEAM_MIN_ITEMS_CLOSEST)) return false;
     best->found = false; best->t = RR_FLT_MAX; best->item = -1; best->face = 0u; best->key = 0.0f;
     float key; int idx;
     while (beam_next(sk, item, &key, &idx)) {

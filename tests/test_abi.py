@@ -69,7 +69,8 @@ def test_struct_sizes_match_header():
 
 
 def test_sample_count_limit():
-    """u16 `(samples + 2).next_power_of_two()` of the reference overflows beyond 32766; the library stops at RR_MAX_SAMPLES."""
+    """u16 `(samples + 2).next_power_of_two()` of the reference overflows beyond 32766 (RR_MAX_SAMPLES_WITH_TABLE: accepted with the
+    caller's table, tests/test_gpu_limits.py); the built-in table stops at RR_MAX_SAMPLES."""
     xy = np.zeros((20000, 2), np.uint16)
     cs = C.c_uint32(0)
     assert capi.lib().rr_sample_table(C.c_uint16(16383), xy.ctypes.data_as(C.c_void_p), C.byref(cs)) == -2

@@ -30,13 +30,20 @@ def test_tiny_and_lopsided_frames(hip, oracle, w, h, spp):
 
 
 def test_deepest_recursion_the_abi_accepts(hip, oracle):
-    """max_recursion = RR_MAX_RECURSION (16): two glass spheres facing each other keep every path alive to the last level."""
+    """max_recursion 16 on the branching spheres scene (two glass spheres facing each other keep every path alive to the last
+    level), and RR_MAX_RECURSION = 30 (31 depth levels: five bits of depth in a shadow record) on mirrors that spawn one child per
+    hit; 31 is refused."""
     fs = load_scene("spheres")
     out, st = _check(hip, oracle, fs, 48, 48, make_config(samples=1, monte_carlo=False, seed=0, max_recursion=16))
     assert st["secondary_rays"] > 4 * st["primary_rays"]
+    mirrors = load_scene("spheres_room")              # a closed room: no ray leaves
+    for m in mirrors.materials:
+        m.alpha, m.reflectivity = 1.0, 0.9        # no refraction child: chains of 30 reflections, not trees
+    out, st = _check(hip, oracle, mirrors, 24, 24, make_config(samples=2, monte_carlo=True, seed=1, max_recursion=30))
+    assert st["secondary_rays"] == 30 * st["primary_rays"]
     with hip.DeviceScene(fs, 0) as ds:
         with pytest.raises(hip.RustrayHipError) as e:
-            ds.render(camera_for(fs, 8, 8).c_struct(), make_config(samples=1, max_recursion=17))
+            ds.render(camera_for(fs, 8, 8).c_struct(), make_config(samples=1, max_recursion=31))
         assert e.value.code == -2
 
 
@@ -49,9 +56,29 @@ def test_many_samples_on_a_small_frame(hip, oracle):
         out = ds.render(cam, cfg)
         assert ds.stats()["primary_rays"] == 8 * 6 * 4096
         with pytest.raises(hip.RustrayHipError) as e:
-            ds.render(cam, make_config(samples=16383))
+            ds.render(cam, make_config(samples=16383))          # beyond the BUILT-IN table's limit (RR_MAX_SAMPLES)
         assert e.value.code == -2
     ref = oracle.render(fs.c_struct(), cam, cfg, n_threads=8)
+    res = compare_frames(out, ref)
+    assert res["n_rgb_over"] == 0 and res["n_id_diff"] == 0, res
+
+
+def test_the_references_own_sample_limit_with_the_callers_table(hip, oracle):
+    """With the caller's sub-sample table the reference's own limit applies: 32766 samples (the u16 `(samples + 2).next_power_of_two()`
+    overflows from 32767 on, src/raytracing.rs:297).  4x3 pixels, cell_size 16384, a table of random cells; 32767 is refused."""
+    fs = load_scene("spheres")
+    cam = camera_for(fs, 4, 3).c_struct()
+    n = 32766
+    rng = np.random.default_rng(8)
+    table = rng.integers(0, 16384, (n, 2)).astype(np.uint16)
+    cfg = make_config(samples=n, monte_carlo=True, seed=9, max_recursion=2)
+    with hip.DeviceScene(fs, 0) as ds:
+        out = ds.render(cam, cfg, sample_xy=table)
+        assert ds.stats()["primary_rays"] == 12 * n
+        with pytest.raises(hip.RustrayHipError) as e:
+            ds.render(cam, make_config(samples=32767), sample_xy=np.zeros((32767, 2), np.uint16))
+        assert e.value.code == -2
+    ref = oracle.render(fs.c_struct(), cam, cfg, sample_xy=table, n_threads=8)
     res = compare_frames(out, ref)
     assert res["n_rgb_over"] == 0 and res["n_id_diff"] == 0, res
 
