@@ -165,6 +165,8 @@ def test_hip_matches_the_reference_rendering(hip, oracle, name):
 # indistinguishable from the control on the WHOLE frame of all three shots.  So the binary of 2022-05 did not sample the
 # seed-0 table the source at HEAD builds (src/raytracing.rs:290-313) or this library's restatement of it; what the shots pin is
 # the distribution of the offsets (cells of the cell_size grid, [0, 1) px right of and above the pixel centre), not the table.
+# (tools/ref_shot_tables.py: eight other plausible fixed tables are rejected the same way, and the reference's edge residuals
+# are uncorrelated between neighbouring pixels like a table drawn per pixel, not like one table per frame.)
 # The table is an INPUT of the boundary (rr_render's sample_xy): a Rust host passes its own.
 #
 # The 2022 shadow semantic (finding 2) is a compatibility switch of the PRODUCT (rr_scene_set_compat), so the shipped
