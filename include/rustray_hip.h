@@ -380,6 +380,14 @@ int rr_deinterleave_device(uint32_t width, uint32_t height, uint32_t tile_w, uin
                            uint32_t n_ranks, uint32_t elem_bytes, const void* src_device,
                            void* dst_device, int device, void* hip_stream);
 
+/* The same for the gathered PACKS of a multi-rank frame, all buffers in one launch and without a concatenation pass: rank r's pack
+ * (a byte buffer) starts at packs + r * pack_stride and holds, for output buffer k (0 rgba8, 1 normal, 2 depth, 3 object id), that
+ * rank's compact pixels at section_offset[k] (elem_bytes[k] bytes per pixel; 0 = the buffer is absent, dst[k] ignored).  dst[k]: the
+ * frame-order buffer.  This is what rank 0 runs on the target of its one gather per frame (rustray_amd/renderer.py: TiledFrame). */
+int rr_deinterleave_packed_device(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t n_ranks,
+                                  const void* packs_device, uint64_t pack_stride, const uint64_t* section_offset,
+                                  const uint32_t* elem_bytes, void* const* dst_device, int device, void* hip_stream);
+
 /* Single-ray query at the pixel centre (reference src/raytracing.rs:237-273). */
 int rr_pick(rr_scene* scene, const rr_camera* camera, int x, int y, rr_pick_result* out);
 

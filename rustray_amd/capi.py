@@ -22,7 +22,7 @@ _LIB = None
 EXPORTS = ["rr_abi_version", "rr_device_count", "rr_last_error", "rr_scene_create", "rr_scene_destroy", "rr_scene_update_transforms",
            "rr_scene_update_materials", "rr_scene_set_tuning", "rr_scene_get_tuning", "rr_scene_set_compat",
            "rr_sample_table", "rr_render", "rr_render_multi", "rr_multi_lock_order", "rr_render_progressive", "rr_region_pixel_count", "rr_render_region_device",
-           "rr_deinterleave_device", "rr_pick", "rr_trace_rays", "rr_scene_last_stats", "rr_post_process", "rr_post_process_device"]
+           "rr_deinterleave_device", "rr_deinterleave_packed_device", "rr_pick", "rr_trace_rays", "rr_scene_last_stats", "rr_post_process", "rr_post_process_device"]
 
 
 class RustrayHipError(RuntimeError):
@@ -275,6 +275,19 @@ def render_multi(device_scenes, cam: rr_camera, cfg: rr_config, sample_xy=None, 
 def deinterleave_device(width, height, tile_w, tile_h, n_ranks, elem_bytes, src_ptr, dst_ptr, device, stream_ptr=None):
     _check(lib().rr_deinterleave_device(width, height, tile_w, tile_h, n_ranks, elem_bytes, C.c_void_p(src_ptr),
                                         C.c_void_p(dst_ptr), device, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+
+def deinterleave_packed_device(width, height, tile_w, tile_h, n_ranks, packs_ptr, pack_stride, section_offset, elem_bytes, dst_ptrs, device, stream_ptr=None):
+    """rr_deinterleave_packed_device: the gathered packs of all ranks -> the frame-order buffers, one launch.  section_offset / elem_bytes /
+    dst_ptrs: 4 entries (rgba, normal, depth, object id); elem_bytes 0 = absent."""
+    so = (C.c_uint64 * 4)(*[int(v) for v in section_offset])
+    eb = (C.c_uint32 * 4)(*[int(v) for v in elem_bytes])
+    dp = (C.c_void_p * 4)(*[C.c_void_p(int(v)) if v else None for v in dst_ptrs])
+    L = lib()
+    L.rr_deinterleave_packed_device.argtypes = [C.c_uint32] * 5 + [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                                                C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
+    _check(L.rr_deinterleave_packed_device(width, height, tile_w, tile_h, n_ranks, C.c_void_p(packs_ptr), C.c_uint64(pack_stride), so, eb, dp,
+                                           device, C.c_void_p(stream_ptr) if stream_ptr else None))
 
 
 def post_process(rgba: np.ndarray, normal, object_id, cavity: bool, outline: bool, device: int = 0) -> np.ndarray:

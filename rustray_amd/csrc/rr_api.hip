@@ -1348,6 +1348,51 @@ extern "C" int rr_deinterleave_device(uint32_t width, uint32_t height, uint32_t 
     return RR_OK;
 }
 
+// The gathered packs of a multi-rank frame -> the four frame-order buffers, one launch (k_gather_packed).
+struct GatherMap2 { DevBuf rank, local; uint32_t w, h, tw, th, n; int device; };
+static std::vector<GatherMap2*> g_gather_maps2;
+extern "C" int rr_deinterleave_packed_device(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t n_ranks,
+                                             const void* packs, uint64_t pack_stride, const uint64_t* section_offset, const uint32_t* elem_bytes,
+                                             void* const* dst, int device, void* hip_stream) {
+    rr_region probe{tile_w, tile_h, n_ranks, 0};
+    int rc = check_region(width, height, &probe);
+    if (rc != RR_OK) return rc;
+    if (!packs || !section_offset || !elem_bytes || !dst) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
+    DPackedGather g{};
+    for (int k = 0; k < 4; k++) {
+        if (elem_bytes[k] & 3u) return fail(RR_ERR_INVALID_ARGUMENT, "elem_bytes[%d] = %u is not a multiple of 4", k, elem_bytes[k]);
+        if (elem_bytes[k] && !dst[k]) return fail(RR_ERR_INVALID_ARGUMENT, "dst[%d] is NULL for a present buffer", k);
+        if ((section_offset[k] & 3u) || (pack_stride & 3u)) return fail(RR_ERR_INVALID_ARGUMENT, "sections and packs must be 4-byte aligned");
+        g.words[k] = elem_bytes[k] / 4u; g.words_total += g.words[k]; g.section[k] = section_offset[k]; g.dst[k] = (uint32_t*)dst[k];
+    }
+    if (g.words_total == 0) return fail(RR_ERR_INVALID_ARGUMENT, "no buffer to move");
+    HIP_TRY(hipSetDevice(device));
+    std::lock_guard<std::mutex> lk(g_gather_mu);
+    GatherMap2* gm = nullptr;
+    for (GatherMap2* m : g_gather_maps2)
+        if (m->w == width && m->h == height && m->tw == tile_w && m->th == tile_h && m->n == n_ranks && m->device == device) gm = m;
+    const uint32_t np = width * height;
+    if (!gm) {
+        std::vector<uint32_t> rank(np), local(np), xy;
+        for (uint32_t r = 0; r < n_ranks; r++) {
+            rr_region rg{tile_w, tile_h, n_ranks, r};
+            fill_region(width, height, rg, &xy);
+            for (uint32_t p = 0; p < xy.size(); p++) { const size_t o = (size_t)(xy[p] >> 16) * width + (xy[p] & 0xffffu); rank[o] = r; local[o] = p; }
+        }
+        gm = new GatherMap2{DevBuf(), DevBuf(), width, height, tile_w, tile_h, n_ranks, device};
+        HIP_TRY(gm->rank.reserve((size_t)np * 4)); HIP_TRY(gm->local.reserve((size_t)np * 4));
+        HIP_TRY(hipMemcpy(gm->rank.p, rank.data(), (size_t)np * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(gm->local.p, local.data(), (size_t)np * 4, hipMemcpyHostToDevice));
+        g_gather_maps2.push_back(gm);
+    }
+    g.src_rank = gm->rank.as<uint32_t>(); g.src_local = gm->local.as<uint32_t>();
+    g.packs = (const char*)packs; g.pack_stride = pack_stride; g.n_pixels = np;
+    const uint64_t total = (uint64_t)np * g.words_total;
+    hipLaunchKernelGGL(k_gather_packed, dim3((uint32_t)((total + RR_BLOCK - 1) / RR_BLOCK)), dim3(RR_BLOCK), 0, (hipStream_t)hip_stream, g);
+    HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
 // Lock order of a set of scene handles: by address (std::less is a total order on pointers).
 static std::vector<rr_scene*> multi_lock_order(rr_scene* const* scenes, uint32_t n) {
     std::vector<rr_scene*> v(scenes, scenes + n);

@@ -2158,6 +2158,29 @@ __global__ __launch_bounds__(RR_BLOCK) void k_gather_frame(const uint32_t* __res
     dst[i] = src[(uint64_t)src_index[p] * elem_words + w];
 }
 
+// The same for the gathered PACKS of a multi-rank frame (TiledFrame: every rank's byte buffer holds one section per output buffer,
+// each section sized for the largest rank): all four buffers in ONE launch, straight from the gather target -- no concatenation
+// pass, no launch per buffer.  src_rank / src_local: for every frame pixel, the rank that rendered it and its position in that
+// rank's compact order.  A thread moves one 4-byte word; the words of a pixel are (rgba, normal.xyz, depth, object id) = 6.
+struct DPackedGather {
+    const uint32_t* src_rank; const uint32_t* src_local;
+    const char* packs; unsigned long long pack_stride;   // rank r's pack starts at packs + r * pack_stride
+    unsigned long long section[4];                       // byte offset of each buffer's section inside a pack
+    uint32_t words[4];                                   // 4-byte words per pixel of each buffer (0 = absent)
+    uint32_t* dst[4];
+    uint32_t n_pixels, words_total;
+};
+__global__ __launch_bounds__(RR_BLOCK) void k_gather_packed(DPackedGather g) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (unsigned long long)g.n_pixels * g.words_total) return;
+    const uint32_t p = (uint32_t)(i / g.words_total);
+    uint32_t w = (uint32_t)(i % g.words_total);
+    uint32_t b = 0;
+    while (w >= g.words[b]) { w -= g.words[b]; b++; } // (absent buffers have 0 words: skipped)
+    const uint32_t* src = (const uint32_t*)(g.packs + (unsigned long long)g.src_rank[p] * g.pack_stride + g.section[b]);
+    g.dst[b][(unsigned long long)p * g.words[b] + w] = src[(unsigned long long)g.src_local[p] * g.words[b] + w];
+}
+
 // ---------------------------------------------------------------------------
 // kernel 7: post-processing (reference src/post_processing.rs:24-181), one thread per pixel.
 // HBM-bound: 24 algorithmic bytes per pixel (RGBA in + normal + object id + RGBA out; the 4-neighbour

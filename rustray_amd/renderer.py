@@ -267,12 +267,12 @@ class TiledFrame:
             view = self._pack[off: off + n * width].view(getattr(torch, dt))
             self._parts[name] = view.reshape(n, comps) if comps > 1 else view.reshape(n)
             off += self.max_count * width
-        total = sum(self.counts)
         self._pack_cpu = torch.zeros_like(self._pack, device="cpu").pin_memory() if (via_cpu and torch.cuda.is_available()) else (torch.zeros_like(self._pack, device="cpu") if via_cpu else None)
-        self._gbuf = self._cat = self._frame = None
+        self._gbuf = self._gbuf_dev = self._frame = None
         if self.world_size > 1 and self.rank == 0:
             self._gbuf = torch.zeros((self.world_size, max(pack_bytes, 4)), dtype=torch.uint8, device="cpu" if via_cpu else device)
-            self._cat = {name: torch.zeros(total * width, dtype=torch.uint8, device=device) for name, _, _, width in spec}
+            if via_cpu and torch.device(device).type == "cuda":
+                self._gbuf_dev = torch.zeros_like(self._gbuf, device=device)   # gloo rehearsal: the gathered packs copied to the card once
         if self.rank == 0:
             self._frame = {name: torch.zeros((self.height * self.width, comps), dtype=getattr(torch, dt), device=device) for name, dt, comps, _ in spec}
         self._alloc_key = key
@@ -293,7 +293,7 @@ class TiledFrame:
             for k in keys:
                 self._parts[k].copy_(parts[k].reshape(self._parts[k].shape))
         dev = self._pack.device
-        gathered = None
+        gathered, packs = None, self._pack   # world_size 1: this rank's own pack is the only one
         if self.world_size > 1:
             send = self._pack
             if via_cpu:
@@ -303,27 +303,31 @@ class TiledFrame:
             dist.gather(send, gl, dst=0)
             if self.rank != 0:
                 return None
-            gathered = {}
-            for k in keys:
-                off, width, dt, comps = self._section[k]
-                rows = [self._gbuf[r, off: off + self.counts[r] * width] for r in range(self.world_size)]
-                if via_cpu:
-                    self._cat[k].copy_(torch.cat(rows))
-                else:
-                    torch.cat(rows, out=self._cat[k])
-                gathered[k] = self._cat[k].view(dt).reshape(-1, comps)
+            packs = self._gbuf
+            if via_cpu and use_device_kernel and dev.type == "cuda":
+                self._gbuf_dev.copy_(self._gbuf)
+                packs = self._gbuf_dev
         out = {}
+        if use_device_kernel and packs.is_cuda:
+            # ONE launch for all buffers, straight from the gather target (rr_deinterleave_packed_device): no concatenation pass
+            names = [sp[0] for sp in self._SPEC]
+            so = [self._section[n][0] if n in keys else 0 for n in names]
+            eb = [self._section[n][1] if n in keys else 0 for n in names]
+            dp = [self._frame[n].data_ptr() if n in keys else 0 for n in names]
+            capi.deinterleave_packed_device(self.width, self.height, self.tile_w, self.tile_h, self.world_size, packs.data_ptr(),
+                                            packs.stride(0) if packs.dim() == 2 else packs.numel(), so, eb, dp,
+                                            packs.device.index or 0, torch.cuda.current_stream().cuda_stream)
+            for k in keys:
+                out[k] = self._frame[k].reshape(self.height, self.width, -1)
+            return out
         for k in keys:
             off, width, dt, comps = self._section[k]
-            cat = gathered[k] if gathered is not None else self._parts[k].reshape(self.n_pixels(), comps)
-            if use_device_kernel and cat.is_cuda:
-                frame = self._frame[k]
-                capi.deinterleave_device(self.width, self.height, self.tile_w, self.tile_h, self.world_size,
-                                         width, cat.data_ptr(), frame.data_ptr(),
-                                         cat.device.index or 0, torch.cuda.current_stream().cuda_stream)
+            if self.world_size > 1:
+                rows = [packs[r, off: off + self.counts[r] * width] for r in range(self.world_size)]
+                cat = torch.cat(rows).view(dt).reshape(-1, comps)
             else:
-                frame = cat.index_select(0, self._frame_index(cat.device))
-            out[k] = frame.reshape(self.height, self.width, -1)
+                cat = self._parts[k].reshape(self.n_pixels(), comps)
+            out[k] = cat.index_select(0, self._frame_index(cat.device)).reshape(self.height, self.width, -1)
         return out
 
 

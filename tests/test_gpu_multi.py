@@ -88,3 +88,35 @@ def test_multi_reports_how_the_buffers_travelled_and_concurrent_callers_do_not_d
     finally:
         for s in scenes:
             s.close()
+
+
+def test_packed_deinterleave_equals_the_per_buffer_form(hip):
+    """rr_deinterleave_packed_device (all buffers of all ranks' packs in one launch, what rank 0 runs on its gather target) against
+    rr_render's frame, for 1 and 3 ranks whose packs are laid out exactly as TiledFrame lays them out."""
+    import torch
+    from rustray_amd.renderer import TiledFrame, render_region_torch
+    fs = load_scene("spheres")
+    w, h = 100, 61
+    cam = camera_for(fs, w, h).c_struct()
+    cfg = make_config(samples=2, monte_carlo=True, seed=8)
+    with hip.DeviceScene(fs, 0) as ds:
+        whole = ds.render(cam, cfg)
+        for world in (1, 3):
+            tfs = [TiledFrame(w, h, r, world, 32, 8) for r in range(world)]
+            for tf in tfs:
+                render_region_torch(ds, cam, cfg, tf, aux=True)
+            torch.cuda.synchronize()
+            tf0 = tfs[0]
+            packs = torch.stack([tf._pack for tf in tfs]).contiguous()       # what dist.gather leaves on rank 0
+            names = [sp[0] for sp in TiledFrame._SPEC]
+            hip.deinterleave_packed_device(w, h, 32, 8, world, packs.data_ptr(), packs.stride(0), [tf0._section[n][0] for n in names],
+                                           [tf0._section[n][1] for n in names], [tf0._frame[n].data_ptr() for n in names], 0,
+                                           torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            for key in ("rgba", "normal", "depth", "object_id"):
+                got = tf0._frame[key].cpu().numpy().reshape(whole[key].shape)
+                assert np.array_equal(got.view(np.uint8), whole[key].view(np.uint8)), (world, key)
+            # and through TiledFrame.gather itself for the one-rank case
+            if world == 1:
+                out = tf0.gather(tf0._parts, use_device_kernel=True)
+                assert np.array_equal(out["rgba"].cpu().numpy().reshape(h, w, 4), whole["rgba"])
