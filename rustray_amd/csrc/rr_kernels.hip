@@ -391,7 +391,8 @@ struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool foun
                 if (ray_triangle(mk3(tr.t0.x, tr.t0.y, tr.t0.z), mk3(tr.t1.x, tr.t1.y, tr.t1.z),               \
                                  mk3(tr.t1.w, tr.t2.x, tr.t2.y), ray, &t, &side)) {                            \
                     const uint32_t face = __float_as_uint(tr.t0.w);                                            \
-                    if (!best.found || t < best.t || (t == best.t && face < best.face)) {                      \
+                    /* (best starts at (FLT_MAX, face 0xffffffff): the first hit always wins without asking best.found) */ \
+                    if (t < best.t || (t == best.t && face < best.face)) {                                     \
                         best.found = true; best.t = t; best.slot = (slot_); best.face = face; best.side = side; \
                     }                                                                                          \
                 }                                                                                              \
@@ -562,6 +563,15 @@ RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, flo
                     if (t <= limit) within = true;                                                             \
                 }                                                                                              \
             }
+// the child test of RR_CHILD with ONE compare (entry <= min(exit, bound): the same predicate; a lane mask less to combine on the
+// scalar unit, which the packet walk leans on) and the raw entry distance as the key (only hit children's keys are read)
+#define RR_PK_CHILD(k_, h_, nx, ny, nz, fx, fy, fz)                                                            \
+        {                                                                                                      \
+            const float tn_ = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));                                           \
+            const float tf_ = fminf(fminf(fx, fy), fminf(fz, RR_FLT_MAX));                                     \
+            h_ = tn_ * 0.999996f <= fminf(tf_ * 1.000004f, bound_);                                            \
+            k_ = tn_;                                                                                          \
+        }
 // one uniform node: tests, leaves, and the choice of the next node.  BOUND: the lane's pruning bound; TEST: the triangle macro;
 // LIVE: the lane still wants hits (any-hit walks drop a lane once it is decided)
 #define RR_PK_NODE(BOUND, TEST, LIVE)                                                                          \
@@ -572,15 +582,13 @@ RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, flo
         float k0 = 0.0f, k1 = 0.0f, k2 = 0.0f, k3 = 0.0f;                                                      \
         if (LIVE) {                                                                                            \
             const float bound_ = (BOUND);                                                                      \
-            const float inf_ = __builtin_inff();                                                               \
             RR_ROW(rnx, sr.o.x, sr.inv.x, nx01, nx23) RR_ROW(rfx, sr.o.x, sr.inv.x, fx01, fx23)                \
             RR_ROW(rny, sr.o.y, sr.inv.y, ny01, ny23) RR_ROW(rfy, sr.o.y, sr.inv.y, fy01, fy23)                \
             RR_ROW(rnz, sr.o.z, sr.inv.z, nz01, nz23) RR_ROW(rfz, sr.o.z, sr.inv.z, fz01, fz23)                \
-            RR_CHILD(kk0, hh0, nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x)                                 \
-            RR_CHILD(kk1, hh1, nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y)                                 \
-            RR_CHILD(kk2, hh2, nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x)                                 \
-            RR_CHILD(kk3, hh3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y)                                 \
-            h0 = hh0; h1 = hh1; h2 = hh2; h3 = hh3; k0 = kk0; k1 = kk1; k2 = kk2; k3 = kk3;                    \
+            RR_PK_CHILD(k0, h0, nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x)                                \
+            RR_PK_CHILD(k1, h1, nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y)                                \
+            RR_PK_CHILD(k2, h2, nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x)                                \
+            RR_PK_CHILD(k3, h3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y)                                \
         }                                                                                                      \
         const int c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w); \
         const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);   \
@@ -589,19 +597,25 @@ RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, flo
         if (m1 != 0ull && c1 < 0) RR_PK_LEAF(c1, h1, TEST)                                                     \
         if (m2 != 0ull && c2 < 0) RR_PK_LEAF(c2, h2, TEST)                                                     \
         if (m3 != 0ull && c3 < 0) RR_PK_LEAF(c3, h3, TEST)                                                     \
-        /* inner children: keyed by the entry distance of the first lane that hits them (non-negative floats order as integers) */ \
-        uint32_t q0 = 0xffffffffu, q1 = 0xffffffffu, q2 = 0xffffffffu, q3 = 0xffffffffu;                       \
-        if (m0 != 0ull && c0 >= 0) q0 = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(k0), __ffsll((long long)m0) - 1); \
-        if (m1 != 0ull && c1 >= 0) q1 = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(k1), __ffsll((long long)m1) - 1); \
-        if (m2 != 0ull && c2 >= 0) q2 = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(k2), __ffsll((long long)m2) - 1); \
-        if (m3 != 0ull && c3 >= 0) q3 = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(k3), __ffsll((long long)m3) - 1); \
-        int e0 = c0, e1 = c1, e2 = c2, e3 = c3;                                                                \
-        /* scalar five-exchange network on (key, child) */                                                     \
-        RR_SCSWAP(q0, e0, q1, e1) RR_SCSWAP(q2, e2, q3, e3) RR_SCSWAP(q0, e0, q2, e2) RR_SCSWAP(q1, e1, q3, e3) RR_SCSWAP(q1, e1, q2, e2) \
-        if (q3 != 0xffffffffu) { if (lane_ == 0u) RR_PK_STK(sp) = e3; sp++; }                                   \
-        if (q2 != 0xffffffffu) { if (lane_ == 0u) RR_PK_STK(sp) = e2; sp++; }                                   \
-        if (q1 != 0xffffffffu) { if (lane_ == 0u) RR_PK_STK(sp) = e1; sp++; }                                   \
-        if (q0 != 0xffffffffu) cur = e0;                                                                       \
+        /* inner children that some lane hits: none or one (most steps) needs no order; otherwise they are keyed by the entry distance */ \
+        /* of the first lane that hits them (non-negative floats order as integers) and sorted in scalar registers */ \
+        const bool i0 = m0 != 0ull && c0 >= 0, i1 = m1 != 0ull && c1 >= 0, i2 = m2 != 0ull && c2 >= 0, i3 = m3 != 0ull && c3 >= 0; \
+        const int n_in = (int)i0 + (int)i1 + (int)i2 + (int)i3;                                                \
+        if (n_in == 1) cur = i0 ? c0 : (i1 ? c1 : (i2 ? c2 : c3));                                             \
+        else if (n_in > 1) {                                                                                   \
+            uint32_t q0 = 0xffffffffu, q1 = 0xffffffffu, q2 = 0xffffffffu, q3 = 0xffffffffu;                   \
+            if (i0) q0 = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(k0), __ffsll((long long)m0) - 1);  \
+            if (i1) q1 = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(k1), __ffsll((long long)m1) - 1);  \
+            if (i2) q2 = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(k2), __ffsll((long long)m2) - 1);  \
+            if (i3) q3 = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(k3), __ffsll((long long)m3) - 1);  \
+            int e0 = c0, e1 = c1, e2 = c2, e3 = c3;                                                            \
+            RR_SCSWAP(q0, e0, q1, e1) RR_SCSWAP(q2, e2, q3, e3) RR_SCSWAP(q0, e0, q2, e2) RR_SCSWAP(q1, e1, q3, e3) RR_SCSWAP(q1, e1, q2, e2) \
+            if (q3 != 0xffffffffu) { if (lane_ == 0u) RR_PK_STK(sp) = e3; sp++; }                               \
+            if (q2 != 0xffffffffu) { if (lane_ == 0u) RR_PK_STK(sp) = e2; sp++; }                               \
+            if (lane_ == 0u) RR_PK_STK(sp) = e1;                                                               \
+            sp++;                                                                                              \
+            cur = e0;                                                                                          \
+        }                                                                                                      \
         else if (sp > sp_base) { sp--; __builtin_amdgcn_wave_barrier(); cur = __builtin_amdgcn_readfirstlane(RR_PK_STK(sp)); } \
         else cur = RR_SENTINEL;                                                                                \
     }
