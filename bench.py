@@ -201,9 +201,17 @@ def extras(args, ds, camc, cfg, step, fence):
 def one_process_main(args):
     """rr_render_multi over --gpus devices from ONE host process (no torch, no torch.distributed): one handle per device,
     one host thread per device inside the call, peer-to-peer copies into device 0, one host copy.  As a helper of an N-rank
-    run it builds everything, then waits for "go" on stdin so that the N ranks are idle while it is timed."""
+    run it prepares the scene on the host, then waits for "go" on stdin: rank 0 says it when the N ranks' run is over and
+    the other ranks have left their GPUs."""
     from rustray_amd import capi
     n = args.gpus
+    fs, cam, cfg = build_workload(args.scene, args.width, args.height, args.spp, args.monte_carlo, args.scene_root)   # (host work only)
+    camc = cam.c_struct()
+    if args.one_process_helper:
+        # nothing of this process touches a GPU before "go": the N ranks' timed region sees no allocation, upload or build of ours
+        line = sys.stdin.readline()
+        if line.strip() != "go":
+            return
     n_dev = capi.device_count()
     if n_dev < 1:
         raise SystemExit("bench.py --one-process needs a GPU")
@@ -211,14 +219,8 @@ def one_process_main(args):
     if max(devices) >= n_dev:
         print(json.dumps({"error": f"{n} devices asked, {n_dev} visible"}), flush=True)
         return
-    fs, cam, cfg = build_workload(args.scene, args.width, args.height, args.spp, args.monte_carlo, args.scene_root)
-    camc = cam.c_struct()
     scenes = [capi.DeviceScene(fs, d) for d in devices]
     try:
-        if args.one_process_helper:
-            line = sys.stdin.readline()
-            if line.strip() != "go":
-                return
         for _ in range(max(args.warmup, 1)):
             capi.render_multi(scenes, camc, cfg, aux=not args.rgba_only)
         t0 = time.perf_counter()
@@ -261,7 +263,7 @@ def start_one_process_helper(args, world):
 
 
 def finish_one_process_helper(helper, timeout=300):
-    """Rank 0, after the timed region (the other ranks wait at a barrier): let the helper run its frames, return its line."""
+    """Rank 0, after the collective is torn down (the other ranks are leaving): let the helper build its handles and run its frames, return its line."""
     import subprocess
     if not hasattr(helper, "communicate"):
         return {"error": f"helper did not start: {helper}"}
@@ -409,8 +411,6 @@ def main():
         if rank == 0:   # the same frame on this rank's GPU alone: the tiled frame must be bit-identical to it
             whole = ds.render(camc, cfg, aux=False)
             dist_info["frame_checksum_single_gpu"] = int(whole["rgba"].astype(np.int64).sum())
-            if helper is not None:
-                dist_info["one_process"] = finish_one_process_helper(helper)
         dist.barrier()
 
     if rank == 0:
@@ -491,11 +491,17 @@ def main():
             result.update(dist_info)
         if world == 1 and not args.no_extras:
             result.update(extras(args, ds, camc, cfg, step, fence))
-        print(json.dumps(result))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     ds.close()
+    if rank == 0:
+        if helper is not None:
+            # the one-process leg runs now: the collective is torn down, this rank's handle is closed and the other ranks are
+            # exiting, so rr_render_multi has the N devices to itself (a rank waiting in an RCCL barrier would spin on its GPU)
+            time.sleep(2.0)
+            result["one_process"] = finish_one_process_helper(helper)
+        print(json.dumps(result))
 
 
 if __name__ == "__main__":
