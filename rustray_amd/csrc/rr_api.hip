@@ -76,7 +76,7 @@ struct DevBuf {
 };
 
 struct TimedLaunch { hipEvent_t a, b; int kind; };
-struct ItemHost { uint32_t kind; int32_t material, material_cache; bool visible, flip_normals, mesh_has_normals, mesh_degenerate; };
+struct ItemHost { uint32_t kind; int32_t material, material_cache; bool visible, flip_normals, mesh_has_normals, mesh_degenerate; int32_t mesh; };
 
 struct rr_scene {
     int device = 0;
@@ -88,6 +88,8 @@ struct rr_scene {
     std::vector<DItem> h_items;
     std::vector<uint32_t> h_slot_face; // per mesh triangle: leaf-order slot -> original face index (rr_trace_rays reports the reference's face id)
     std::vector<ItemHost> item_host; // what rr_scene_update_materials needs to rebuild the item flag words
+    // the vertex positions of every mesh (xyz; empty: more than RR_TIGHT_BOX_MAX_VERTICES of them, or a non-finite one), for the items' world boxes
+    std::vector<std::vector<float>> mesh_points;
     std::vector<uint32_t> tex_width;
     std::vector<DTexture> h_textures; // descriptors of the uploaded images (copied into the material records, make_dmaterial)
     uint32_t n_materials = 0;
@@ -394,16 +396,48 @@ static void fill_item_matrices(DItem& d, const float* trans, const float* inv) {
 // Far from the origin, or with a badly conditioned transform, this is orders of magnitude more than float spacing
 // (tools/fuzz_parity.py far: a sheared sphere 1e5 away needs 15 units on a 10-unit box); on ordinary scenes it is
 // ~1e-6 of the scene size.  An inverse with a projective bottom row gets an unbounded box (always a candidate).
-struct WorldBox { double lo[3], hi[3]; };
-static WorldBox exact_world_box(const DItem& it) {
+//
+// Tighter than the corners, for meshes: a mesh only ever contributes through a triangle its own tree lets the ray reach (a candidate
+// whose box is hit and whose triangles are missed changes nothing: src/raytracing.rs:471-487 looks at `intersect`'s result only),
+// and the walks of rr_kernels.hip test a triangle only under a leaf box that the local ray passes -- boxes of the mesh's own
+// vertices, padded by 4e-6 of their coordinates (rr_bvh.cpp).  So whatever the triangle test then reports, NaN included, it
+// reports for a ray that passes the padded box of the mesh's VERTICES; in world space that is the box of the transformed
+// vertices, which for a rotated item is much smaller than the box of the rotated local box (a unit cube turned by 45 degrees
+// about two axes: 1.7 x per axis).  The world box is the intersection of the two, grown by the leaf padding mapped to world
+// space; the padding of padded_world_box (how far the f32 local ray sits from the true one) applies as before.
+// NOT for balls: ray_ball has no box in front of it, and where its arithmetic overflows (a tiny ball: local coordinates
+// ~1e12) it answers Some(NaN) for ANY ray that passes the local box -- tests/golden/fuzz_568 holds such a scene -- so a ball
+// keeps the box of its local box's corners.  Not for a mesh whose tree is a single leaf either (nothing is culled in front of
+// its triangles).  `points`: the mesh's vertex positions, or NULL.
+#define RR_TIGHT_BOX_MAX_VERTICES 262144u
+struct WorldBox { double lo[3], hi[3]; bool tight[3]; double ext[3]; }; // tight[r]: axis r comes from the vertices; ext: largest |local coordinate| per local axis
+static WorldBox exact_world_box(const DItem& it, const std::vector<float>* points) {
     WorldBox b;
     const float4 rows[3] = {it.tr0, it.tr1, it.tr2};
-    for (int r = 0; r < 3; r++) { b.lo[r] = 1e300; b.hi[r] = -1e300; }
+    for (int r = 0; r < 3; r++) { b.lo[r] = 1e300; b.hi[r] = -1e300; b.tight[r] = false; b.ext[r] = 0.0; }
     for (int c = 0; c < 8; c++) {
         const double p[3] = {(c & 1) ? it.bmax[0] : it.bmin[0], (c & 2) ? it.bmax[1] : it.bmin[1], (c & 4) ? it.bmax[2] : it.bmin[2]};
         for (int r = 0; r < 3; r++) {
             const double v = (double)rows[r].x * p[0] + (double)rows[r].y * p[1] + (double)rows[r].z * p[2] + (double)rows[r].w;
             b.lo[r] = std::min(b.lo[r], v); b.hi[r] = std::max(b.hi[r], v);
+        }
+    }
+    if (!(it.flags & RR_IF_SPHERE) && it.root4 >= 0 && points && !points->empty()) {
+        const float* p = points->data();
+        const size_t n = points->size() / 3;
+        double* ext = b.ext; // largest |coordinate| per local axis: what the leaf padding is relative to
+        for (size_t i = 0; i < n; i++)
+            for (int c = 0; c < 3; c++) ext[c] = std::max(ext[c], std::fabs((double)p[3 * i + c]));
+        for (int r = 0; r < 3; r++) {
+            const double mx = rows[r].x, my = rows[r].y, mz = rows[r].z;
+            double lo = 1e300, hi = -1e300;
+            for (size_t i = 0; i < n; i++) {
+                const double v = mx * p[3 * i] + my * p[3 * i + 1] + mz * p[3 * i + 2];
+                lo = std::min(lo, v); hi = std::max(hi, v);
+            }
+            const double leaf_pad = 2.0e-5 * (std::fabs(mx) * ext[0] + std::fabs(my) * ext[1] + std::fabs(mz) * ext[2]) + 1e-30;
+            const double tlo = lo + (double)rows[r].w - leaf_pad, thi = hi + (double)rows[r].w + leaf_pad;
+            if (std::isfinite(tlo) && std::isfinite(thi) && tlo <= thi && (tlo > b.lo[r] || thi < b.hi[r])) { b.lo[r] = std::max(b.lo[r], tlo); b.hi[r] = std::min(b.hi[r], thi); b.tight[r] = true; }
         }
     }
     return b;
@@ -424,6 +458,15 @@ static void padded_world_box(const DItem& it, const WorldBox& b, const double re
         double et = M[r][3], at = 0.0;
         for (int k = 0; k < 3; k++) { et += M[r][k] * N[k][3]; at += std::fabs(M[r][k]) * std::fabs(N[k][3]); }
         pad += std::fabs(et) + g * at;
+        if (b.tight[r]) {
+            // a leaf's slab test lets a ray through whose entry and exit distances differ by up to 8e-6 of themselves (RR_CHILD): planes moved
+            // by that share of the way travelled along a local axis, which is at most the local reach plus the mesh's own extent
+            for (int c = 0; c < 3; c++) {
+                double way = std::fabs(N[c][3]) + b.ext[c];
+                for (int k = 0; k < 3; k++) way += std::fabs(N[c][k]) * 2.0 * reach[k];
+                pad += std::fabs(M[r][c]) * 1.0e-5 * way;
+            }
+        }
         pad = 2.0 * pad + 1e-6 * std::max(std::fabs(b.lo[r]), std::fabs(b.hi[r])) + 1e-30; // + float rounding of the box and of the walk's plane distances
         lo[r] = (float)(b.lo[r] - pad); hi[r] = (float)(b.hi[r] + pad);
         if (!affine || !std::isfinite(lo[r]) || lo[r] < -3.0e38f) lo[r] = -3.0e38f;
@@ -441,20 +484,47 @@ static int build_tlas(rr_scene* s, const double want_reach[3], std::vector<DNode
         *root4 = (int32_t)0x80000000; // RR_SENTINEL
         return RR_OK;
     }
-    std::vector<WorldBox> exact(n);
+    // two boxes per item: the box of its local box's corners -- what the tree is built over and what shadow packets are tested against:
+    // the shadow query orders items by the distance at which the LOCAL box is entered, and prunes by it, which only a world box that
+    // contains the local box bounds from below -- and the box of its surface (exact_world_box), which the closest-hit packets use:
+    // there an item matters through its nearest hit alone, and that lies in the tighter box
+    std::vector<WorldBox> exact(n), surf(n);
     for (uint32_t i = 0; i < n; i++) {
-        exact[i] = exact_world_box(s->h_items[i]);
+        const int32_t mesh = i < s->item_host.size() ? s->item_host[i].mesh : -1;
+        exact[i] = exact_world_box(s->h_items[i], nullptr);
+        surf[i] = exact_world_box(s->h_items[i], (mesh >= 0 && (size_t)mesh < s->mesh_points.size()) ? &s->mesh_points[(size_t)mesh] : nullptr);
         for (int c = 0; c < 3; c++) {
             const double m = std::max(std::fabs(exact[i].lo[c]), std::fabs(exact[i].hi[c])) * 1.001 + 0.01; // + the shadow bias along the normal
             if (std::isfinite(m)) s->tlas_reach[c] = std::max(s->tlas_reach[c], m);
         }
     }
-    std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
-    for (uint32_t i = 0; i < n; i++) padded_world_box(s->h_items[i], exact[i], s->tlas_reach, &lo[3 * (size_t)i], &hi[3 * (size_t)i]);
-    s->h_item_boxes.resize(2 * (size_t)n);
+    // Can some ball's ray_toi_with_ball overflow (b * b, a * c beyond f32: delta = NaN and the ball answers Some(NaN))?  Judged with six
+    // orders of magnitude to spare on the ray directions; a hint for trace_shadow_blockers only (the closest-hit walks detect the NaN itself).
+    s->view.compat &= ~RR_VIEW_NAN_BALLS;
     for (uint32_t i = 0; i < n; i++) {
+        const DItem& it = s->h_items[i];
+        if (!(it.flags & RR_IF_SPHERE)) continue;
+        const float4 rows[3] = {it.inv0, it.inv1, it.inv2};
+        double nmax = 0.0, tmax = 0.0;
+        for (int r = 0; r < 3; r++) {
+            nmax = std::max(nmax, std::fabs((double)rows[r].x) + std::fabs((double)rows[r].y) + std::fabs((double)rows[r].z));
+            tmax = std::max(tmax, std::fabs((double)rows[r].w));
+        }
+        const double reach = std::max(s->tlas_reach[0], std::max(s->tlas_reach[1], s->tlas_reach[2]));
+        const double on = nmax * reach + tmax, dn = nmax * 1e6, rad = std::fabs((double)it.radius);
+        const bool affine = it.inv3.x == 0.0f && it.inv3.y == 0.0f && it.inv3.z == 0.0f && it.inv3.w == 1.0f;
+        if (!affine || !(on * dn < 1e18) || !(rad * dn < 1e18) || !(on < 1e18) || !(rad < 1e18)) s->view.compat |= RR_VIEW_NAN_BALLS;
+    }
+    std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
+    s->h_item_boxes.resize(4 * (size_t)n); // [0, 2n): corner boxes (lo, hi); [2n, 4n): surface boxes
+    for (uint32_t i = 0; i < n; i++) {
+        padded_world_box(s->h_items[i], exact[i], s->tlas_reach, &lo[3 * (size_t)i], &hi[3 * (size_t)i]);
         s->h_item_boxes[2 * (size_t)i] = make_float4(lo[3 * (size_t)i], lo[3 * (size_t)i + 1], lo[3 * (size_t)i + 2], 0.0f);
         s->h_item_boxes[2 * (size_t)i + 1] = make_float4(hi[3 * (size_t)i], hi[3 * (size_t)i + 1], hi[3 * (size_t)i + 2], 0.0f);
+        float tl[3], th[3];
+        padded_world_box(s->h_items[i], surf[i], s->tlas_reach, tl, th);
+        s->h_item_boxes[2 * ((size_t)n + i)] = make_float4(tl[0], tl[1], tl[2], 0.0f);
+        s->h_item_boxes[2 * ((size_t)n + i) + 1] = make_float4(th[0], th[1], th[2], 0.0f);
     }
     rr::BvhResult r;
     if (!rr::build_bvh(lo.data(), hi.data(), n, 1, s->tlas_depth_limit, &r))
@@ -680,6 +750,15 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         }
     }
 
+    s->mesh_points.assign(fs->n_meshes, std::vector<float>());
+    for (uint32_t mi = 0; mi < fs->n_meshes; mi++) {
+        const rr_mesh& m = fs->meshes[mi];
+        if (m.n_vertices == 0u || m.n_vertices > RR_TIGHT_BOX_MAX_VERTICES) continue;
+        bool finite = true;
+        for (size_t k = 0; k < 3 * (size_t)m.n_vertices && finite; k++) finite = std::isfinite(m.positions[k]);
+        if (finite) s->mesh_points[mi].assign(m.positions, m.positions + 3 * (size_t)m.n_vertices);
+    }
+
     // ---- items
     s->h_items.resize(fs->n_items);
     s->item_host.resize(fs->n_items);
@@ -698,7 +777,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         d.id = it.id;
         d.material = it.material;
         ItemHost& ih = s->item_host[i];
-        ih = ItemHost{it.kind, it.material, it.material_cache, it.visible != 0, it.flip_normals != 0, false, false};
+        ih = ItemHost{it.kind, it.material, it.material_cache, it.visible != 0, it.flip_normals != 0, false, false, it.kind != RR_ITEM_SPHERE ? (int32_t)it.mesh : -1};
         if (it.kind != RR_ITEM_SPHERE) {
             const MeshDev& m = md[it.mesh];
             d.tri_base = m.tri_base; d.n_tris = m.n_tris;
@@ -1287,7 +1366,7 @@ extern "C" int rr_scene_set_compat(rr_scene* s, uint32_t flags) {
     if (!s) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
     if (flags & ~RR_COMPAT_OCCLUDER_ALPHA_SHADOWS) return fail(RR_ERR_INVALID_ARGUMENT, "unknown compatibility flags 0x%x", flags);
     std::lock_guard<std::mutex> lk(s->mu);
-    s->view.compat = flags; // the scene view is passed to the kernels by value with every launch
+    s->view.compat = (s->view.compat & RR_VIEW_NAN_BALLS) | flags; // the scene view is passed to the kernels by value with every launch
     return RR_OK;
 }
 

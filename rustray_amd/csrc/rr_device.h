@@ -127,10 +127,12 @@ struct DSceneView {
     uint32_t n_enabled_lights; // any number; level 1 uses fixed shadow slots for up to RR_FIXED_SLOT_LIGHTS of them
     const DNode4* tnodes4;  // the top level over item world boxes, same form (one item per leaf)
     int32_t tlas_root4;      // node index, a leaf code (one item), or RR_SENTINEL (empty scene)
-    const float4* item_boxes; // the same padded world boxes per item: [2 i] = lo, [2 i + 1] = hi (the packet form of the top level, trace_closest_packet)
+    const float4* item_boxes; // padded world boxes per item for the packet form of the top level: [2 i] = lo, [2 i + 1] = hi of the item's corner box (the boxes of
+                              // the tree; trace_shadow_packet), [2 (n_items + i)], [.. + 1] of its surface box (trace_closest_packet); rr_api.hip build_tlas
     uint32_t any_alpha_occluder; // some item's material has an alpha map: the shadow attenuation of a receiver whose uv may be NaN can be NaN (k_shade, want_shadow)
     uint32_t general_w;      // some trans_inv has a w row other than (0,0,0,1)
-    uint32_t compat;         // RR_COMPAT_* (rr_scene_set_compat): behaviours of earlier reference binaries; 0 = the source at HEAD
+    uint32_t compat;         // RR_COMPAT_* (rr_scene_set_compat): behaviours of earlier reference binaries; 0 = the source at HEAD.
+                             // RR_VIEW_NAN_BALLS (library-internal, build_tlas): some ball's arithmetic can overflow into a NaN toi
 };
 
 // ---- per-frame constants ----------------------------------------------------------------
@@ -165,6 +167,7 @@ struct DRayQueue {
 //   s1 = (dir.xyz, bits(receiver item | depth << 27))   the receiver's material alpha is looked up for occluded rays only
 //   s2 = (contribution rgb, bits(accumulator slot))
 // scenes whose top level has a packet form (rr_kernels.hip: beam_candidates)
+#define RR_VIEW_NAN_BALLS 0x80000000u // DSceneView::compat
 #define RR_BEAM_MAX_ITEMS 512u // 8 passes of 64 boxes: about what three steps of the per-ray walk cost
 #define RR_BEAM_MIN_ITEMS 17u  // up to 16 items the tree is two levels: the per-ray walk is cheaper than the packet's set-up (shadow rays)
 #ifndef RR_BEAM_MIN_ITEMS_CLOSEST

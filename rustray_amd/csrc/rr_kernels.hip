@@ -697,7 +697,7 @@ RR_DEV bool item_passes(uint32_t flags, bool for_shadow, uint32_t depth) {
     return true;
 }
 
-struct Closest { float t; int item; uint32_t face; float key; bool found; };
+struct Closest { float t; int item; uint32_t face; float key; bool found; bool nan_seen; }; // nan_seen: a ball answered Some(NaN) (trace_closest_ordered)
 
 // The reference sorts candidates by bbox distance (stable) and keeps strictly
 // smaller toi, so among equal toi the smaller (bbox distance, item index) wins.
@@ -716,6 +716,7 @@ RR_DEV void closest_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t dep
     if (flags & RR_IF_SPHERE) {
         bool inside;
         if (!ray_ball(it.radius, lr, solid, &t, &inside)) return;
+        if (t != t) { best->nan_seen = true; return; } // Some(NaN): what it does to the result depends on the candidate ORDER (trace_closest_ordered)
         face = 0u;
     } else {
         if (it.n_tris == 0u) return;
@@ -761,7 +762,7 @@ RR_DEV void closest_item_packet(const DSceneView& sc, int idx, f3 o, f3 d, uint3
 #endif
 
 RR_DEV void trace_closest_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, int* s_stack, Closest* best) {
-    best->found = false; best->t = RR_FLT_MAX; best->item = -1; best->face = 0u; best->key = 0.0f;
+    best->found = false; best->nan_seen = false; best->t = RR_FLT_MAX; best->item = -1; best->face = 0u; best->key = 0.0f;
     // top level: world-space boxes over items (stands in for Scene::get_possible_hits_by_ray,
     // reference src/scene.rs:1715-1722; any conservative candidate set gives the same result)
     // the top level in the 4-wide form of the per-mesh trees, same step (sentinel-terminated stack)
@@ -792,7 +793,7 @@ RR_DEV bool ray_nonfinite(f3 o, f3 d) {
     return z != 0.0f;
 }
 RR_DEV void trace_closest_nonfinite(const DSceneView& sc, f3 o, f3 d, uint32_t depth, Closest* best) {
-    best->found = false; best->t = RR_FLT_MAX; best->item = -1; best->face = 0u; best->key = 0.0f;
+    best->found = false; best->nan_seen = false; best->t = RR_FLT_MAX; best->item = -1; best->face = 0u; best->key = 0.0f;
     Closest first = *best; // the first candidate in the reference's order that is hit at all
     for (int idx = 0; idx < (int)sc.n_items; idx++) {
         const DItem& it = rr_global(sc.items)[idx];
@@ -808,6 +809,42 @@ RR_DEV void trace_closest_nonfinite(const DSceneView& sc, f3 o, f3 d, uint32_t d
         }
     }
     if (first.found && first.t != first.t) *best = first; // a NaN toi is never replaced (`toi < best` is false)
+}
+
+// A FINITE ray can get Some(NaN) from a ball too: where ray_toi_with_ball's products overflow (a ball of radius 1e12 under a
+// transform that shrinks it to one unit: b * b = inf, a * c = inf, delta = NaN, every comparison false).  The reference's loop
+// (src/raytracing.rs:466-487) walks the candidates in (bbox distance, item) order and replaces its best hit on `toi < best`: a NaN
+// hit is THE result if it is the first candidate hit at all in that order (nothing compares smaller than NaN afterwards) and is
+// ignored otherwise.  The walks above visit candidates in another order and keep a minimum, which is only order-free while every
+// toi is a number; they leave a NaN hit out and flag the ray (Closest::nan_seen), and the flagged rays -- none in any scene whose
+// balls have sane sizes -- take this pass over all items in the reference's own terms.
+RR_DEV void trace_closest_ordered(const DSceneView& sc, f3 o, f3 d, uint32_t depth, int* s_stack, Closest* best) {
+    Closest fin; fin.found = false; fin.nan_seen = false; fin.t = RR_FLT_MAX; fin.item = -1; fin.face = 0u; fin.key = 0.0f;
+    Closest first = fin; // the first candidate in the reference's order that is hit at all
+    for (int idx = 0; idx < (int)sc.n_items; idx++) {
+        const DItem& it = rr_global(sc.items)[idx];
+        const uint32_t flags = it.flags;
+        if (!item_passes(flags, false, depth)) continue;
+        const LRay lr = inverse_ray(it, o, d, sc.general_w != 0u);
+        const bool solid = (flags & RR_IF_SOLID_BASE) != 0u;
+        float key, t; uint32_t face = 0u;
+        if (!aabb_cast(it.bmin, it.bmax, lr, solid, &key) || key != key) continue;
+        if (flags & RR_IF_SPHERE) {
+            bool inside;
+            if (!ray_ball(it.radius, lr, solid, &t, &inside)) continue;
+        } else {
+            if (it.n_tris == 0u) continue;
+            TriBest tb;
+            blas_closest<true>(sc, it, lr, RR_FLT_MAX, s_stack, 0, &tb);
+            if (!tb.found) continue;
+            t = tb.t; face = tb.slot | (tb.side << 30);
+        }
+        if (!first.found || key < first.key || (key == first.key && idx < first.item)) { first.found = true; first.t = t; first.item = idx; first.face = face; first.key = key; }
+        if (t == t && (!fin.found || t < fin.t || (t == fin.t && (key < fin.key || (key == fin.key && idx < fin.item))))) {
+            fin.found = true; fin.t = t; fin.item = idx; fin.face = face; fin.key = key;
+        }
+    }
+    *best = (first.found && first.t != first.t) ? first : fin;
 }
 
 // ---------------------------------------------------------------------------
@@ -851,7 +888,10 @@ RR_DEV void beam_axis(bool neg, float blo, float bhi, float olo, float ohi, floa
 // The candidate list of a packet: lane l of the wave holds candidate l as (sort key, item); the key keeps the upper bits
 // of the distance at which the item's box can first be entered by any ray of the packet (a lower bound) and the lane in
 // its low six bits, 0xffffffff = none.  `far`: (wave-uniform) boxes that start beyond it are of no interest.
-RR_DEV bool beam_candidates(const DSceneView& sc, f3 o, f3 d, float far, int* s_stack, uint32_t* sk_out, int* item_out, uint32_t min_items = RR_BEAM_MIN_ITEMS) {
+// `boxes`: sc.item_boxes (the items' corner boxes: shadow packets, whose order and bounds are the LOCAL boxes' entry distances, which only a world box
+// around the local box bounds from below) or sc.item_boxes + 2 * n_items (their surface boxes: closest-hit packets; rr_api.hip build_tlas).
+// (A shadow packet that also dropped the items whose surface box none of its rays reaches gained nothing: 6.00 -> 6.02 ms.)
+RR_DEV bool beam_candidates(const DSceneView& sc, const float4* __restrict__ boxes, f3 o, f3 d, float far, int* s_stack, uint32_t* sk_out, int* item_out, uint32_t min_items = RR_BEAM_MIN_ITEMS) {
     const uint32_t n_items = sc.n_items;
     if (n_items > RR_BEAM_MAX_ITEMS || n_items < min_items) return false;
     // coherent: finite rays, no zero direction component, one sign per axis
@@ -872,7 +912,7 @@ RR_DEV bool beam_candidates(const DSceneView& sc, f3 o, f3 d, float far, int* s_
         const uint32_t j = base + lane;
         bool cand = false; float key = 0.0f;
         if (j < n_items) {
-            const float4 lo = sc.item_boxes[2u * j], hi = sc.item_boxes[2u * j + 1u];
+            const float4 lo = boxes[2u * j], hi = boxes[2u * j + 1u];
             float tnx, tfx, tny, tfy, tnz, tfz;
             beam_axis(negx, lo.x, hi.x, oxl, oxh, axl, axh, &tnx, &tfx);
             beam_axis(negy, lo.y, hi.y, oyl, oyh, ayl, ayh, &tny, &tfy);
@@ -907,8 +947,8 @@ RR_DEV bool beam_next(uint32_t& sk, int item, float* key, int* idx) {
 }
 RR_DEV bool trace_closest_packet(const DSceneView& sc, f3 o, f3 d, uint32_t depth, int* s_stack, Closest* best) {
     uint32_t sk; int item;
-    if (!beam_candidates(sc, o, d, RR_FLT_MAX, s_stack, &sk, &item, RR_BEAM_MIN_ITEMS_CLOSEST)) return false;
-    best->found = false; best->t = RR_FLT_MAX; best->item = -1; best->face = 0u; best->key = 0.0f;
+    if (!beam_candidates(sc, sc.item_boxes + 2u * sc.n_items, o, d, RR_FLT_MAX, s_stack, &sk, &item, RR_BEAM_MIN_ITEMS_CLOSEST)) return false;
+    best->found = false; best->nan_seen = false; best->t = RR_FLT_MAX; best->item = -1; best->face = 0u; best->key = 0.0f;
     float key; int idx;
     while (beam_next(sk, item, &key, &idx)) {
         // the remaining boxes all start at or behind this one: done when that is behind every lane's best hit
@@ -940,7 +980,7 @@ RR_DEV void shadow_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t dept
     bool any = false, within = false; float t = 0.0f; uint32_t face = 0u;
     if (flags & RR_IF_SPHERE) {
         bool inside;
-        if (ray_ball(it.radius, lr, false, &t, &inside)) { any = true; within = t <= limit; }
+        if (ray_ball(it.radius, lr, false, &t, &inside)) { any = true; within = !(t > limit); } // (`in_light = toi > len`, :890: false for a NaN toi)
     } else if (it.n_tris != 0u) {
         if (flags & RR_IF_OCCLUDER_ALPHA_TEX) { // the occluder's alpha map needs the true nearest hit
             TriBest tb;
@@ -982,26 +1022,35 @@ RR_DEV void shadow_item_packet(const DSceneView& sc, int idx, f3 o, f3 d, uint32
 
 // Second pass of a shadow query: is there an item whose box starts BEYOND the light (skipped above), ordered before
 // the selected occluder (sel), that is hit at all?  The reference tries candidates in bbox-distance order and the
-// first one that is hit decides (src/raytracing.rs:466-487); its hit lies beyond the light, so the receiver is lit.
-RR_DEV bool shadow_blocker_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t depth, float limit, const ShadowSel& sel,
-                                int* s_stack, int sp_base) {
+// first one that is hit decides (src/raytracing.rs:466-487); its hit lies beyond the light, so the receiver is lit --
+// unless it is a ball whose arithmetic overflowed into Some(NaN): `in_light = toi > len` is false for that, the receiver is
+// in ITS shadow (trace_closest_ordered has the story).  Returns 0: no blocker, 1: a hit beyond the light, 2: a NaN hit.
+RR_DEV int shadow_blocker_item(const DSceneView& sc, int idx, f3 o, f3 d, uint32_t depth, float limit, const ShadowSel& sel,
+                               int* s_stack, int sp_base, float* key_out) {
     const DItem& it = rr_global(sc.items)[idx];
     const uint32_t flags = it.flags;
-    if (!item_passes(flags, true, depth)) return false;
+    if (!item_passes(flags, true, depth)) return 0;
     LRay lr = inverse_ray(it, o, d, sc.general_w != 0u);
     float key, tmin;
-    if (!aabb_cast2(it.bmin, it.bmax, lr, false, &key, &tmin)) return false;
-    if (key != key || !(tmin > limit * RR_TOI_SLACK)) return false;
-    if (!(key < sel.key || (key == sel.key && idx < sel.item))) return false;
-    if (flags & RR_IF_SPHERE) { float t; bool inside; return ray_ball(it.radius, lr, false, &t, &inside); }
-    if (it.n_tris == 0u) return false;
+    if (!aabb_cast2(it.bmin, it.bmax, lr, false, &key, &tmin)) return 0;
+    if (key != key || !(tmin > limit * RR_TOI_SLACK)) return 0;
+    if (!(key < sel.key || (key == sel.key && idx < sel.item))) return 0;
+    *key_out = key;
+    if (flags & RR_IF_SPHERE) { float t; bool inside; return ray_ball(it.radius, lr, false, &t, &inside) ? (t != t ? 2 : 1) : 0; }
+    if (it.n_tris == 0u) return 0;
     bool any = false, within = false;
     blas_any(sc, it, lr, RR_FLT_MAX, s_stack, sp_base, &any, &within);
-    return any;
+    return any ? 1 : 0;
 }
 
-RR_DEV bool trace_shadow_blockers(const DSceneView& sc, f3 o, f3 d, uint32_t depth, float limit, const ShadowSel& sel, int* s_stack) {
-    const float bound = sel.key * 1.00001f + 1e-6f; // a blocker's box starts before the occluder's key
+// Updates *sel to the outcome: lit (within = false) if the first blocker in the reference's order has a hit beyond the light, in the
+// shadow of that blocker if its toi is NaN, untouched without a blocker.  A scene without balls that can overflow (RR_VIEW_NAN_BALLS,
+// the usual case) is done at the first blocker found: they all say "lit".
+RR_DEV void trace_shadow_blockers(const DSceneView& sc, f3 o, f3 d, uint32_t depth, float limit, ShadowSel* sel, int* s_stack) {
+    const float bound = sel->key * 1.00001f + 1e-6f; // a blocker's box starts before the occluder's key
+    const bool nan_balls = (sc.compat & RR_VIEW_NAN_BALLS) != 0u;
+    ShadowSel first = *sel; // the first blocker in (key, item) order so far; starts as the occluder it must precede
+    int first_kind = 0;
     const Slab4 ws = make_slab4(make_slab(o, d), 0u);
     int sp = 1;
     STK(0) = RR_SENTINEL;
@@ -1009,10 +1058,17 @@ RR_DEV bool trace_shadow_blockers(const DSceneView& sc, f3 o, f3 d, uint32_t dep
     for (;;) {
         while (cur >= 0) { RR_NODE4_STEP_PLAIN(sc.tnodes4, ws, bound) }
         if (cur == RR_SENTINEL) break;
-        if (shadow_blocker_item(sc, (int)RR_LEAF_FIRST((uint32_t)~cur), o, d, depth, limit, sel, s_stack, sp)) return true;
+        const int idx = (int)RR_LEAF_FIRST((uint32_t)~cur);
+        float key = 0.0f;
+        const int kind = shadow_blocker_item(sc, idx, o, d, depth, limit, first, s_stack, sp, &key);
+        if (kind != 0) {
+            first.key = key; first.item = idx; first_kind = kind;
+            if (!nan_balls) break;
+        }
         sp--; cur = STK(sp);
     }
-    return false;
+    if (first_kind == 1) sel->within = false;
+    else if (first_kind == 2) { sel->key = first.key; sel->item = first.item; sel->within = true; sel->t = __uint_as_float(0x7fc00000u); sel->face = 0u; }
 }
 
 // A non-finite shadow ray (a NaN normal puts the origin at NaN) in the reference: every candidate sphere reports Some(NaN)
@@ -1053,21 +1109,21 @@ RR_DEV void trace_shadow_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, f
     }
     // The occluder found has a hit within the light distance.  Only if its sort key lies beyond the light (its box
     // contains the ray origin, so the key is the box EXIT distance) can an item that starts beyond the light precede it.
-    if (sel->found && sel->within && sel->key > limit && trace_shadow_blockers(sc, o, d, depth, limit, *sel, s_stack)) sel->within = false;
+    if (sel->found && sel->within && sel->key > limit) trace_shadow_blockers(sc, o, d, depth, limit, sel, s_stack);
 }
 
 // The packet form of trace_shadow_ray's first pass (see trace_closest_packet): candidates in box-distance order, until the
 // next box starts beyond every lane's bound (the light, or the key of the occluder selected so far).
 RR_DEV bool trace_shadow_packet(const DSceneView& sc, f3 o, f3 d, uint32_t depth, float limit, int* s_stack, ShadowSel* sel) {
     uint32_t sk; int item;
-    if (!beam_candidates(sc, o, d, wave_max_f32(limit == limit ? limit : 0.0f), s_stack, &sk, &item)) return false;
+    if (!beam_candidates(sc, sc.item_boxes, o, d, wave_max_f32(limit == limit ? limit : 0.0f), s_stack, &sk, &item)) return false;
     sel->found = false; sel->within = false; sel->key = 0.0f; sel->item = -1; sel->t = 0.0f; sel->face = 0u;
     float key; int idx;
     while (beam_next(sk, item, &key, &idx)) {
         if (__ballot(key <= RR_SHADOW_BOUND) == 0ull) break; // (a NaN light distance compares false: that lane wants nothing, as in the per-ray walk)
         shadow_item_packet(sc, idx, o, d, depth, limit, s_stack, sel);
     }
-    if (sel->found && sel->within && sel->key > limit && trace_shadow_blockers(sc, o, d, depth, limit, *sel, s_stack)) sel->within = false;
+    if (sel->found && sel->within && sel->key > limit) trace_shadow_blockers(sc, o, d, depth, limit, sel, s_stack);
     return true;
 }
 
@@ -1504,6 +1560,7 @@ __global__ __launch_bounds__(RR_BLOCK, RR_CLOSEST_WAVES) void k_trace_closest(DS
             if (ray_nonfinite(ro, rd)) trace_closest_nonfinite(sc, ro, rd, depth, &best);
             else trace_closest_ray(sc, ro, rd, depth, s_stack, &best);
         }
+        if (best.nan_seen) trace_closest_ordered(sc, ro, rd, depth, s_stack, &best); // (rare: a ball whose arithmetic overflows)
         if (i < n) q.hit[i] = make_uint4(__float_as_uint(best.t), (uint32_t)(best.found ? best.item : -1), best.face, 0u);
     }
 }

@@ -65,11 +65,13 @@ def test_create_destroy_does_not_leak_device_memory(hip):
         with hip.DeviceScene(fs, 0) as ds:
             ds.render(cam, cfg)
     cycle()  # first use: code objects, the de-interleave maps, torch's context
-    free0 = free_bytes()
-    for _ in range(12):
-        cycle()
-    free1 = free_bytes()
-    assert free0 - free1 < (4 << 20), f"{(free0 - free1) / 2**20:.1f} MiB lost over 12 create / destroy cycles"
+    lost = []
+    for _ in range(3):   # a leak loses memory in EVERY window; the HIP runtime growing one of its own pools (seen: 16 MiB, once) shows in one
+        free0 = free_bytes()
+        for _ in range(12):
+            cycle()
+        lost.append(free0 - free_bytes())
+    assert min(lost) < (4 << 20), f"{[round(v / 2**20, 1) for v in lost]} MiB lost over three windows of 12 create / destroy cycles"
 
 
 def test_material_edits_in_place_equal_a_fresh_scene(hip, oracle):
