@@ -584,6 +584,26 @@ static void camera_reach(const rr_camera* cam, const rr_config* cfg, double need
     }
 }
 
+// Per-triangle constants of the shading (DTri::v1.w, v3), with the IEEE binary32 sequence of rr_math.h's cross3 / dot3 / norm3 /
+// normalize3 as k_shade evaluated them per hit (this file is built without contraction and without fast-math on the host side too;
+// sqrtf and the division are correctly rounded on both; tests/test_gpu_math.py compares the two builds bit for bit):
+//   area = norm3(cross3(a - b, a - c))            Mesh::get_normal / get_uv, src/shape/mesh.rs:127-143 (area_weights)
+//   ng   = normalize3(cross3(b - a, c - a))       the triangle's own normal, src/shape/mesh.rs:76-98
+static void tri_shading_constants(const float* a, const float* b, const float* c, float* ng, float* area) {
+    auto cross = [](const float* u, const float* v, float* r) {
+        r[0] = u[1] * v[2] - u[2] * v[1]; r[1] = u[2] * v[0] - u[0] * v[2]; r[2] = u[0] * v[1] - u[1] * v[0];
+    };
+    auto norm = [](const float* u) { return sqrtf((u[0] * u[0] + u[1] * u[1]) + u[2] * u[2]); };
+    const float amb[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]}, amc[3] = {a[0] - c[0], a[1] - c[1], a[2] - c[2]};
+    float x[3];
+    cross(amb, amc, x);
+    *area = norm(x);
+    const float bma[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, cma[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+    cross(bma, cma, x);
+    const float n = norm(x);
+    ng[0] = x[0] / n; ng[1] = x[1] / n; ng[2] = x[2] / n;
+}
+
 extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** out) {
     if (!out) return fail(RR_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
@@ -718,9 +738,12 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
             }
             DTri t;
             float fbits; memcpy(&fbits, &f, 4);
+            float ng[3], area;
+            tri_shading_constants(a, b, c, ng, &area);
             t.v0 = make_float4(a[0], a[1], a[2], fbits);
-            t.v1 = make_float4(b[0], b[1], b[2], 0.0f);
+            t.v1 = make_float4(b[0], b[1], b[2], area);
             t.v2 = make_float4(c[0], c[1], c[2], 0.0f);
+            t.v3 = make_float4(ng[0], ng[1], ng[2], 0.0f);
             all_tris.push_back(t);
             {   // the edge vectors parry's test evaluates per ray: ab = b - a, ac = c - a
                 const float ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
@@ -1788,6 +1811,14 @@ extern "C" int rr_trace_rays(rr_scene* s, const float* origins, const float* dir
 extern "C" int rr_math_probe(int op, const float* a, const float* b, const float* c, int n, float* out0, float* out1, float* out2,
                              uint64_t seed, int device) {
     if (n <= 0 || !a || !out0) return fail(RR_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (op == 11) { // the HOST build of the per-triangle shading constants (tri_shading_constants): a, b, c hold n / 3 triangles' vertices, xyz interleaved
+        for (int t = 0; t + 2 < n; t += 3) {
+            float ng[3], area;
+            tri_shading_constants(a + t, b + t, c + t, ng, &area);
+            for (int k = 0; k < 3; k++) { out0[t + k] = ng[k]; if (out1) out1[t + k] = area; }
+        }
+        return RR_OK;
+    }
     if (op == 6) { // the HOST build of rr_cos, as make_dmaterial uses it for DMaterial::cos_*: out0[i] = rr_cos(a[i] * pi); needs no device
         for (int i = 0; i < n; i++) out0[i] = rr_cos(a[i] * RR_PI_F);
         return RR_OK;

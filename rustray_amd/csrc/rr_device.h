@@ -38,9 +38,13 @@ struct DNode4 { float4 q[8]; };
 #define RR_STACK_DEPTH (RR_BLAS_MAX_DEPTH + RR_TLAS_MAX_DEPTH + 3)
 #endif
 
-// Triangle for intersection, 48 B (3 x dwordx4), in BVH leaf order:
-//   v0 = (a.xyz, bits(original face index)), v1 = (b.xyz, 0), v2 = (c.xyz, 0)
-struct DTri { float4 v0, v1, v2; };
+// Triangle as the shading of a hit reads it, 64 B (4 x dwordx4), in BVH leaf order:
+//   v0 = (a.xyz, bits(original face index)), v1 = (b.xyz, area), v2 = (c.xyz, 0), v3 = (flat normal.xyz, 0)
+// area = |cross(a - b, a - c)| (Mesh::get_normal / get_uv divide their weights by it, src/shape/mesh.rs:127-143) and the flat normal
+// normalize(cross(b - a, c - a)) (parry's triangle normal, mesh.rs:76-98) are the same IEEE values for every hit of the triangle:
+// the host evaluates them once, with the sequence k_shade used per hit (rr_api.hip tri_shading_constants; a flat, untextured hit
+// then reads v3 alone).
+struct DTri { float4 v0, v1, v2, v3; };
 
 // The same triangle as the walks test it, 48 B = 3 x dwordx4, same order: the edge vectors of parry's ray/triangle
 // test are the same IEEE values for every ray, so the host computes them once (no contraction); the plane normal

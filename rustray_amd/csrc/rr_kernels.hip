@@ -1212,6 +1212,13 @@ RR_DEV void area_weights(f3 a, f3 b, f3 c, f3 p, float* a1, float* a2, float* a3
     *a2 = norm3(cross3(f3v, f1)) / area;
     *a3 = norm3(cross3(f1, f2v)) / area;
 }
+// the same with the triangle's area from the host (DTri::v1.w: the value of the line `area = ...` above, bit for bit)
+RR_DEV void area_weights(f3 a, f3 b, f3 c, f3 p, float area, float* a1, float* a2, float* a3) {
+    f3 f1 = a - p, f2v = b - p, f3v = c - p;
+    *a1 = norm3(cross3(f2v, f3v)) / area;
+    *a2 = norm3(cross3(f3v, f1)) / area;
+    *a3 = norm3(cross3(f1, f2v)) / area;
+}
 RR_DEV f2 sphere_uv(const DItem& it, f3 hit, bool general_w) {
     f3 p = to_local_point(it, hit, general_w);
     float theta = rr_atan2(-(p.z - 0.0f), p.x - 0.0f);
@@ -1684,14 +1691,14 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
             f3 nl = normalize3(lr.o + lr.d * t2);
             normal = to_world_normal(it, inside ? -nl : nl);
         } else {
-            const DTri tr = rr_global(sc.tris)[it_tri_base + slot];
-            const f3 a = mk3(tr.v0.x, tr.v0.y, tr.v0.z), b = mk3(tr.v1.x, tr.v1.y, tr.v1.z), c = mk3(tr.v2.x, tr.v2.y, tr.v2.z);
+            const DTri* trp = &rr_global(sc.tris)[it_tri_base + slot];
             // the area weights of the hit point serve the interpolated normal AND the uv (Mesh::get_normal and
             // Mesh::get_uv compute the same three numbers from the same inputs, src/shape/mesh.rs:105-161, :204-259)
             if ((it_flags & RR_IF_SMOOTH) || (m.flags & RR_MF_ANY_TEX)) {
+                const float4 v0 = trp->v0, v1 = trp->v1, v2 = trp->v2;
                 at = rr_global(sc.attrs)[it_tri_base + slot];
                 const f3 p = to_local_point(it, hit_point, gw);
-                area_weights(a, b, c, p, &a1, &a2, &a3);
+                area_weights(mk3(v0.x, v0.y, v0.z), mk3(v1.x, v1.y, v1.z), mk3(v2.x, v2.y, v2.z), p, v1.w, &a1, &a2, &a3); // v1.w: the triangle's area (host)
                 have_weights = true;
             }
             if (it_flags & RR_IF_SMOOTH) {
@@ -1699,7 +1706,8 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
                 normal = to_world_normal(it, mk3(p1.x + p2.x + p3.x, p1.y + p2.y + p3.y, p1.z + p2.z + p3.z));
                 if (back) normal = -normal;
             } else {
-                f3 ng = normalize3(cross3(b - a, c - a));
+                const float4 v3 = trp->v3; // normalize3(cross3(b - a, c - a)), evaluated once per triangle on the host (DTri)
+                const f3 ng = mk3(v3.x, v3.y, v3.z);
                 normal = to_world_normal(it, neg ? -ng : ng);
             }
             if (it_flags & RR_IF_FLIP_NORMALS) normal = -normal;
@@ -2313,6 +2321,15 @@ __global__ void k_math_probe(int op, const float* a, const float* b, const float
     else if (op == 3) out0[i] = a[i] / b[i];
     else if (op == 4) out0[i] = sqrtf(a[i]);
     else if (op == 7) out0[i] = rr_cos(a[i] * RR_PI_F);
+    else if (op == 10) { // the per-triangle shading constants as k_shade evaluated them per hit (now DTri::v1.w, v3; op 11 is the host's build)
+        const int t = (i / 3) * 3, k = i % 3;
+        if (t + 2 < n) {
+            const f3 va = mk3(a[t], a[t + 1], a[t + 2]), vb = mk3(b[t], b[t + 1], b[t + 2]), vc = mk3(c[t], c[t + 1], c[t + 2]);
+            const f3 ng = normalize3(cross3(vb - va, vc - va));
+            out0[i] = k == 0 ? ng.x : (k == 1 ? ng.y : ng.z);
+            out1[i] = norm3(cross3(va - vb, va - vc));
+        }
+    }
     else if (op == 5) {
         RngKey k; k.seed_lo = seed_lo; k.seed_hi = seed_hi; k.pixel = (uint32_t)i; k.sample = (uint32_t)(i & 7); k.node = 1u + (uint32_t)(i % 5);
         f3 r = jitter(mk3(a[i], b[i], c[i]), 0.05f, rr_cos(0.05f * RR_PI_F), k, (uint32_t)(i % 3));

@@ -64,3 +64,23 @@ def test_host_and_device_builds_of_rr_cos_agree(hip):
     host, _, _ = hip.math_probe(6, x)
     dev, _, _ = hip.math_probe(7, x)
     assert np.array_equal(host.view(np.uint32), dev.view(np.uint32))
+
+
+def test_host_and_device_builds_of_the_triangle_constants_agree(hip):
+    """DTri::v1.w (area) and v3 (the flat normal) are evaluated once per triangle on the host where k_shade evaluated them per hit:
+    the two builds of the same IEEE sequence, bit for bit -- ordinary, sliver, huge, tiny and degenerate triangles."""
+    rng = np.random.default_rng(14)
+    t = 60000
+    a = rng.uniform(-3.0, 3.0, (t, 3)); b = a + rng.uniform(-1.0, 1.0, (t, 3)); c = a + rng.uniform(-1.0, 1.0, (t, 3))
+    k = t // 6
+    c[:k] = a[:k] + (b[:k] - a[:k]) * rng.uniform(0.0, 2.0, (k, 1)) + rng.uniform(-1e-6, 1e-6, (k, 3))    # slivers
+    s = 10.0 ** rng.uniform(-12.0, 9.0, (k, 1))
+    a[k:2 * k] *= s; b[k:2 * k] *= s; c[k:2 * k] *= s                                                  # tiny and huge
+    c[2 * k:2 * k + 50] = b[2 * k:2 * k + 50]                                                          # zero area: 0 / 0
+    a[2 * k + 50:2 * k + 60] = 0.0; b[2 * k + 50:2 * k + 60] = 0.0; c[2 * k + 50:2 * k + 60] = 0.0
+    fa, fb, fc = (np.ascontiguousarray(v, np.float32).reshape(-1) for v in (a, b, c))
+    dn, da, _ = hip.math_probe(10, fa, fb, fc)
+    hn, ha, _ = hip.math_probe(11, fa, fb, fc)
+    assert np.array_equal(dn.view(np.uint32), hn.view(np.uint32))
+    assert np.array_equal(da.view(np.uint32), ha.view(np.uint32))
+    assert np.isnan(hn.reshape(-1, 3)[2 * k:2 * k + 60]).all()   # the degenerate ones: NaN on both sides, as in the reference
