@@ -83,7 +83,7 @@ struct rr_scene {
     int n_cus = 256;
     std::mutex mu;
     // scene data
-    DevBuf items, nodes4, tnodes4, tris, trix, attrs, face_slot, materials, textures, texels, lights;
+    DevBuf items, nodes4, tnodes4, tris, trix, attrs, face_slot, materials, textures, texels, lights, flat_normals;
     DSceneView view{};
     std::vector<DItem> h_items;
     std::vector<uint32_t> h_slot_face; // per mesh triangle: leaf-order slot -> original face index (rr_trace_rays reports the reference's face id)
@@ -584,6 +584,16 @@ static void camera_reach(const rr_camera* cam, const rr_config* cfg, double need
     }
 }
 
+// DSceneView::flat_normals from the items and triangles on the device (k_world_normals); after every upload of the items' transforms
+static int update_flat_normals(rr_scene* s) {
+    const uint32_t n = (uint32_t)s->h_items.size();
+    if (n == 0) return RR_OK;
+    hipLaunchKernelGGL(k_world_normals, dim3(n), dim3(RR_BLOCK), 0, nullptr, s->items.as<DItem>(), n, s->tris.as<DTri>(), s->flat_normals.as<float4>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return RR_OK;
+}
+
 // Per-triangle constants of the shading (DTri::v1.w, v3), with the IEEE binary32 sequence of rr_math.h's cross3 / dot3 / norm3 /
 // normalize3 as k_shade evaluated them per hit (this file is built without contraction and without fast-math on the host side too;
 // sqrtf and the division are correctly rounded on both; tests/test_gpu_math.py compares the two builds bit for bit):
@@ -787,6 +797,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     s->item_host.resize(fs->n_items);
     s->n_materials = fs->n_materials;
     bool general_w = false;
+    uint64_t n_flat_normals = 0; // entries of DSceneView::flat_normals: two per instanced triangle
     for (uint32_t i = 0; i < fs->n_items; i++) {
         const rr_item& it = fs->items[i];
         const rr_material& cache = fs->materials[it.material_cache];
@@ -805,6 +816,8 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
             const MeshDev& m = md[it.mesh];
             d.tri_base = m.tri_base; d.n_tris = m.n_tris;
             d.node_base4 = m.node_base4; d.root4 = m.root4;
+            if (n_flat_normals + 2ull * m.n_tris > 0xffffffffull) return fail(RR_ERR_UNSUPPORTED, "more than 2^31 instanced triangles");
+            d.wn_base = (uint32_t)n_flat_normals; n_flat_normals += 2ull * m.n_tris;
             ih.mesh_has_normals = m.has_normals; ih.mesh_degenerate = m.degenerate;
         }
         const uint32_t f = item_flags(ih, cache, full, s->tex_width);
@@ -842,8 +855,12 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     HIP_TRY(upload(s->attrs, all_attrs.data(), all_attrs.size() * sizeof(DTriAttr)));
     HIP_TRY(upload(s->face_slot, all_face_slot.data(), all_face_slot.size() * 4));
     HIP_TRY(upload(s->items, s->h_items.data(), s->h_items.size() * sizeof(DItem)));
+    HIP_TRY(s->flat_normals.reserve(std::max<size_t>((size_t)n_flat_normals * sizeof(float4), 16)));
+    rc = update_flat_normals(s.get());
+    if (rc != RR_OK) return rc;
 
     DSceneView& v = s->view;
+    v.flat_normals = s->flat_normals.as<float4>();
     v.items = s->items.as<DItem>(); v.nodes4 = s->nodes4.as<DNode4>(); v.tris = s->tris.as<DTri>(); v.trix = s->trix.as<DTriX>(); v.attrs = s->attrs.as<DTriAttr>();
     v.face_slot = s->face_slot.as<uint32_t>();
     v.materials = s->materials.as<DMaterial>(); v.textures = s->textures.as<DTexture>(); v.texels = s->texels.as<uint32_t>();
@@ -883,6 +900,7 @@ extern "C" int rr_scene_update_transforms(rr_scene* s, const float* trans, const
     }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(s->items.p, s->h_items.data(), n * sizeof(DItem), hipMemcpyHostToDevice));
+    { int rc = update_flat_normals(s); if (rc != RR_OK) return rc; }
     s->view.general_w = general_w ? 1u : 0u;
     {
         std::vector<DNode4> tlas4; int32_t root4 = 0;

@@ -82,7 +82,8 @@ struct DItem {
     float bmax[3]; uint32_t flags;
     uint32_t id;         // ShapeBasics::id
     int32_t material;    // index into DMaterial[]
-    uint32_t _r0, _r1;
+    uint32_t wn_base;    // first entry of this item's flat world normals (DSceneView::flat_normals: two per triangle)
+    uint32_t _r1;
     uint32_t tri_base;   // first DTri / DTriX / DTriAttr of the mesh
     uint32_t n_tris;
     uint32_t node_base4; // first DNode4 of the mesh's tree
@@ -121,6 +122,11 @@ struct DSceneView {
     const DTri* tris;       // vertices, for shading
     const DTriX* trix;      // the walks' form
     const DTriAttr* attrs;
+    // The world normal of a flat-shaded hit depends on the item's transform and the triangle only: normalize(trans * (+-flat normal, 0))
+    // (Shape::intersect, src/shape/mesh.rs:76-98).  k_world_normals evaluates it once per instanced triangle and sign -- with the very
+    // device function k_shade used per hit (to_world_normal) -- at scene creation and after a transform update:
+    // flat_normals[item.wn_base + 2 * slot + (negated ? 1 : 0)].xyz.  32 B per instanced triangle.
+    const float4* flat_normals;
     const uint32_t* face_slot; // per mesh triangle: original face index -> leaf-order slot
     const DMaterial* materials;
     const DTexture* textures;

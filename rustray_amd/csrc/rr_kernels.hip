@@ -1706,9 +1706,9 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
                 normal = to_world_normal(it, mk3(p1.x + p2.x + p3.x, p1.y + p2.y + p3.y, p1.z + p2.z + p3.z));
                 if (back) normal = -normal;
             } else {
-                const float4 v3 = trp->v3; // normalize3(cross3(b - a, c - a)), evaluated once per triangle on the host (DTri)
-                const f3 ng = mk3(v3.x, v3.y, v3.z);
-                normal = to_world_normal(it, neg ? -ng : ng);
+                // to_world_normal(it, neg ? -ng : ng) with ng = DTri::v3, evaluated once per instanced triangle by k_world_normals
+                const float4 wn = rr_global(sc.flat_normals)[it.wn_base + 2u * slot + (neg ? 1u : 0u)];
+                normal = mk3(wn.x, wn.y, wn.z);
             }
             if (it_flags & RR_IF_FLIP_NORMALS) normal = -normal;
         }
@@ -1956,6 +1956,21 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
         if (n_shaded) atomicAdd(&counters[RR_CNT_SHADED], (unsigned long long)n_shaded);
         if (n_shadow) atomicAdd(&counters[RR_CNT_SHADOW], (unsigned long long)n_shadow);
         if (n_secondary) atomicAdd(&counters[RR_CNT_SECONDARY], (unsigned long long)n_secondary);
+    }
+}
+
+// The flat world normals of every mesh item (DSceneView::flat_normals): one workgroup per item, both signs of every triangle's
+// normal through the item's transform.  Run at scene creation and after rr_scene_update_transforms.
+__global__ __launch_bounds__(RR_BLOCK) void k_world_normals(const DItem* __restrict__ items, uint32_t n_items, const DTri* __restrict__ tris, float4* __restrict__ out) {
+    if (blockIdx.x >= n_items) return;
+    const DItem& it = items[blockIdx.x];
+    if (it.flags & RR_IF_SPHERE) return;
+    for (uint32_t slot = threadIdx.x; slot < it.n_tris; slot += blockDim.x) {
+        const float4 v3 = tris[it.tri_base + slot].v3;
+        const f3 ng = mk3(v3.x, v3.y, v3.z);
+        const f3 p = to_world_normal(it, ng), m = to_world_normal(it, -ng);
+        out[it.wn_base + 2u * slot] = make_float4(p.x, p.y, p.z, 0.0f);
+        out[it.wn_base + 2u * slot + 1u] = make_float4(m.x, m.y, m.z, 0.0f);
     }
 }
 
