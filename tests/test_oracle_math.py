@@ -66,3 +66,39 @@ def test_host_build_of_rr_cos_equals_the_oracles(oracle):
     s, c = np.zeros_like(arg), np.zeros_like(arg)
     oracle.lib().rro_sincos(arg.ctypes.data_as(C.c_void_p), len(arg), s.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p))
     assert np.array_equal(got.view(np.uint32), c.view(np.uint32))
+
+
+def test_host_build_of_the_triangle_constants_is_the_ieee_sequence():
+    """DTri::v1.w (area = |cross(a - b, a - c)|) and v3 (normalize(cross(b - a, c - a))) are evaluated on the host (rr_api.hip
+    tri_shading_constants).  numpy's float32 arithmetic is the same correctly rounded IEEE sequence: bit for bit, NaN for NaN.
+    (tests/test_gpu_math.py holds the device build to the host build.)"""
+    from rustray_amd import capi
+    L = capi.lib()
+    rng = np.random.default_rng(21)
+    t = 30000
+    a = rng.uniform(-3.0, 3.0, (t, 3)); b = a + rng.uniform(-1.0, 1.0, (t, 3)); c = a + rng.uniform(-1.0, 1.0, (t, 3))
+    k = t // 5
+    c[:k] = a[:k] + (b[:k] - a[:k]) * rng.uniform(0.0, 2.0, (k, 1)) + rng.uniform(-1e-6, 1e-6, (k, 3))
+    s = 10.0 ** rng.uniform(-12.0, 9.0, (k, 1))
+    a[k:2 * k] *= s; b[k:2 * k] *= s; c[k:2 * k] *= s
+    c[2 * k:2 * k + 40] = b[2 * k:2 * k + 40]
+    a, b, c = (np.ascontiguousarray(v, np.float32) for v in (a, b, c))
+    ng, area = np.zeros(3 * t, np.float32), np.zeros(3 * t, np.float32)
+    p = lambda v: v.ctypes.data_as(C.c_void_p)
+    assert L.rr_math_probe(11, p(a), p(b), p(c), 3 * t, p(ng), p(area), None, C.c_uint64(0), 0) == 0
+
+    def cross(u, v):
+        return np.stack([u[:, 1] * v[:, 2] - u[:, 2] * v[:, 1], u[:, 2] * v[:, 0] - u[:, 0] * v[:, 2], u[:, 0] * v[:, 1] - u[:, 1] * v[:, 0]], axis=1)
+
+    def norm(u):
+        return np.sqrt((u[:, 0] * u[:, 0] + u[:, 1] * u[:, 1]) + u[:, 2] * u[:, 2])
+    with np.errstate(all="ignore"):
+        want_area = norm(cross(a - b, a - c))
+        x = cross(b - a, c - a)
+        want_ng = x / norm(x)[:, None]
+    assert want_area.dtype == np.float32 and want_ng.dtype == np.float32
+    assert np.array_equal(area.reshape(t, 3)[:, 0].view(np.uint32), want_area.view(np.uint32))
+    got = ng.reshape(t, 3)
+    same = (got.view(np.uint32) == want_ng.view(np.uint32)) | (np.isnan(got) & np.isnan(want_ng))
+    assert same.all()
+    assert np.isnan(got[2 * k:2 * k + 40]).all()
