@@ -19,6 +19,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <new>
+#include <stdexcept>
 #include <map>
 #include <memory>
 #include <functional>
@@ -34,14 +37,80 @@
 // ---------------------------------------------------------------------------
 static thread_local std::string tl_error;
 
-static int fail(int code, const char* fmt, ...) {
+static int fail(int code, const char* fmt, ...) noexcept {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    tl_error = buf;
+    try { tl_error = buf; } catch (...) { /* no memory for the message: the code still says what happened */ }
     return code;
+}
+
+// ---------------------------------------------------------------------------
+// Nothing unwinds across the C ABI (include/rustray_hip.h: "no function aborts or throws").  The host is Rust built with
+// panic = "abort" (reference Cargo.toml:9-11); a C++ exception that reached one of its frames would be undefined behaviour.
+// Every extern "C" entry point below is a function-try-block that ends in RR_GUARD_END: std::bad_alloc (the std::vectors
+// sized by the caller's scene) becomes RR_ERR_OUT_OF_MEMORY, anything else RR_ERR_DEVICE with what() in rr_last_error().
+// Host worker threads (mesh tree builds, one thread per device in rr_render_multi) run under `Workers`: an exception inside
+// a worker is carried to the calling thread and rethrown there, a thread that cannot be started is not fatal (the caller
+// does that work itself), and the destructor joins -- no path ends in std::terminate.
+// ---------------------------------------------------------------------------
+static int guard_fail(const char* fn) noexcept {
+    try { throw; }
+    catch (const std::bad_alloc&) { return fail(RR_ERR_OUT_OF_MEMORY, "%s: out of host memory", fn); }
+    catch (const std::exception& e) { return fail(RR_ERR_DEVICE, "%s: %s", fn, e.what()); }
+    catch (...) { return fail(RR_ERR_DEVICE, "%s: unknown exception", fn); }
+}
+#define RR_GUARD_END(fn) catch (...) { return guard_fail(fn); }
+
+struct Workers {
+    std::vector<std::thread> threads;
+    std::atomic_flag taken = ATOMIC_FLAG_INIT;
+    std::exception_ptr first; // written by the one worker that wins `taken`, read after join()
+    Workers() = default;
+    Workers(const Workers&) = delete;
+    Workers& operator=(const Workers&) = delete;
+    ~Workers() { join(); }
+    // runs f() on a new thread; false = no thread could be started (the caller runs f itself)
+    template <class F> bool spawn(F f) {
+        try {
+            threads.emplace_back([this, f]() mutable { run(f); });
+            return true;
+        } catch (...) { return false; }
+    }
+    // f() on the calling thread, under the same net
+    template <class F> void run(F& f) noexcept {
+        try { f(); }
+        catch (...) { if (!taken.test_and_set()) first = std::current_exception(); }
+    }
+    void join() noexcept { for (std::thread& t : threads) if (t.joinable()) t.join(); }
+    void join_and_rethrow() { join(); if (first) std::rethrow_exception(first); }
+};
+
+// Test-only fault injection (tests/test_abi.py, tests/test_gpu_guard.py): rr_test_fault("point", kind, skip) arms ONE fault; the
+// (skip + 1)-th crossing of RR_FAULT_POINT("point") on any thread throws std::bad_alloc (kind 1), std::runtime_error (2) or
+// an int (3) and disarms.  Not armed (always, outside the tests): one relaxed atomic load per crossing, and the points sit
+// outside every per-ray and per-triangle loop.
+static std::atomic<int> g_fault_kind{0};
+static std::atomic<int> g_fault_skip{0};
+static char g_fault_point[64] = "";
+static void fault_point(const char* name) {
+    if (g_fault_kind.load(std::memory_order_relaxed) == 0 || strcmp(name, g_fault_point) != 0) return;
+    if (g_fault_skip.fetch_sub(1) > 0) return;
+    const int kind = g_fault_kind.exchange(0);
+    if (kind == 1) throw std::bad_alloc();
+    if (kind == 2) throw std::runtime_error(std::string("injected fault at ") + name);
+    if (kind == 3) throw 42;
+}
+#define RR_FAULT_POINT(name) fault_point(name)
+extern "C" int rr_test_fault(const char* point, int kind, int skip) {
+    g_fault_kind.store(0);
+    if (!point || kind < 0 || kind > 3 || strlen(point) >= sizeof g_fault_point) return fail(RR_ERR_INVALID_ARGUMENT, "rr_test_fault: bad arguments");
+    strcpy(g_fault_point, point);
+    g_fault_skip.store(skip < 0 ? 0 : skip);
+    g_fault_kind.store(kind);
+    return RR_OK;
 }
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
@@ -206,7 +275,7 @@ uint32_t cell_size_of(uint16_t samples) {
 
 } // namespace
 
-extern "C" int rr_sample_table(uint16_t samples, uint16_t* xy_out, uint32_t* cell_size_out) {
+extern "C" int rr_sample_table(uint16_t samples, uint16_t* xy_out, uint32_t* cell_size_out) try {
     if (!xy_out && samples) return fail(RR_ERR_INVALID_ARGUMENT, "rr_sample_table: xy_out is NULL");
     if (samples > RR_MAX_SAMPLES) return fail(RR_ERR_UNSUPPORTED, "samples %u > %u", (unsigned)samples, RR_MAX_SAMPLES);
     uint32_t cs = cell_size_of(samples);
@@ -224,17 +293,17 @@ extern "C" int rr_sample_table(uint16_t samples, uint16_t* xy_out, uint32_t* cel
     }
     if (cell_size_out) *cell_size_out = cs;
     return RR_OK;
-}
+} RR_GUARD_END("rr_sample_table")
 
 // ---------------------------------------------------------------------------
 // misc entry points
 // ---------------------------------------------------------------------------
 extern "C" uint32_t rr_abi_version(void) { return RR_ABI_VERSION; }
-extern "C" int rr_device_count(void) {
+extern "C" int rr_device_count(void) try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
-}
+} RR_GUARD_END("rr_device_count")
 extern "C" const char* rr_last_error(void) { return tl_error.c_str(); }
 
 // xy: the region's pixels in OUTPUT order (tile order, row-major inside the tile; the ABI contract).
@@ -614,7 +683,58 @@ static void tri_shading_constants(const float* a, const float* b, const float* c
     ng[0] = x[0] / n; ng[1] = x[1] / n; ng[2] = x[2] / n;
 }
 
-extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** out) {
+// The binary trees of the meshes are independent: built by a few host threads (a scene of 194 meshes / 559 k triangles:
+// 0.4 s on one core).  The workers pull mesh indices from one counter, so threads that could not be started only mean
+// fewer hands; an exception in any worker (the builder's vectors are sized by the caller's meshes) is rethrown here.
+static void build_mesh_trees(const rr_flat_scene* fs, int depth_limit, std::vector<rr::BvhResult>* built, std::vector<char>* built_ok) {
+    std::atomic<uint32_t> next_mesh{0};
+    auto worker = [&]() {
+        for (;;) {
+            const uint32_t mi = next_mesh.fetch_add(1);
+            if (mi >= fs->n_meshes) break;
+            RR_FAULT_POINT("scene_create.mesh_worker");
+            const rr_mesh& m = fs->meshes[mi];
+            const uint32_t nt = m.n_triangles;
+            std::vector<float> lo(3 * (size_t)nt), hi(3 * (size_t)nt);
+            for (uint32_t f = 0; f < nt; f++)
+                for (int k = 0; k < 3; k++) {
+                    float a = m.positions[3 * (size_t)m.indices[3 * (size_t)f] + k];
+                    float b = m.positions[3 * (size_t)m.indices[3 * (size_t)f + 1] + k];
+                    float c = m.positions[3 * (size_t)m.indices[3 * (size_t)f + 2] + k];
+                    lo[3 * (size_t)f + k] = std::min(a, std::min(b, c));
+                    hi[3 * (size_t)f + k] = std::max(a, std::max(b, c));
+                }
+            (*built_ok)[mi] = rr::build_bvh(lo.data(), hi.data(), nt, RR_MAX_LEAF_TRIS, depth_limit, &(*built)[mi]) ? 1 : 0;
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const uint32_t n_threads = std::min<uint32_t>(std::min<uint32_t>(hw ? hw : 4u, 16u), std::max<uint32_t>(fs->n_meshes, 1u));
+    Workers pool;
+    for (uint32_t t = 1; t < n_threads; t++)
+        if (!pool.spawn(worker)) break;
+    pool.run(worker);
+    pool.join_and_rethrow();
+}
+
+// Test-only (tests/test_abi.py; not in the header): the host half of rr_scene_create -- validation and the threaded mesh tree
+// builds -- without a device, so that the no-throw guard and the worker net can be exercised on a CPU-only box.
+extern "C" int rr_test_host_build(const rr_flat_scene* fs, uint64_t* n_nodes_out) try {
+    int rc = validate_scene(fs);
+    if (rc != RR_OK) return rc;
+    RR_FAULT_POINT("scene_create.host");
+    std::vector<rr::BvhResult> built(fs->n_meshes);
+    std::vector<char> built_ok(fs->n_meshes, 0);
+    build_mesh_trees(fs, RR_BLAS_MAX_DEPTH, &built, &built_ok);
+    uint64_t n = 0;
+    for (uint32_t mi = 0; mi < fs->n_meshes; mi++) {
+        if (!built_ok[mi]) return fail(RR_ERR_UNSUPPORTED, "mesh %u: BVH depth limit exceeded", mi);
+        n += built[mi].nodes.size();
+    }
+    if (n_nodes_out) *n_nodes_out = n;
+    return RR_OK;
+} RR_GUARD_END("rr_test_host_build")
+
+extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** out) try {
     if (!out) return fail(RR_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     int rc = validate_scene(fs);
@@ -624,6 +744,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     if (device < 0 || device >= ndev) return fail(RR_ERR_INVALID_ARGUMENT, "device %d of %d", device, ndev);
     HIP_TRY(hipSetDevice(device));
     std::unique_ptr<rr_scene> s(new rr_scene);
+    RR_FAULT_POINT("scene_create.host");
     s->device = device;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -688,33 +809,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     // 0.4 s on one core), then collapsed and laid out one after the other
     std::vector<rr::BvhResult> built(fs->n_meshes);
     std::vector<char> built_ok(fs->n_meshes, 0);
-    {
-        std::atomic<uint32_t> next_mesh{0};
-        auto worker = [&]() {
-            for (;;) {
-                const uint32_t mi = next_mesh.fetch_add(1);
-                if (mi >= fs->n_meshes) break;
-                const rr_mesh& m = fs->meshes[mi];
-                const uint32_t nt = m.n_triangles;
-                std::vector<float> lo(3 * (size_t)nt), hi(3 * (size_t)nt);
-                for (uint32_t f = 0; f < nt; f++)
-                    for (int k = 0; k < 3; k++) {
-                        float a = m.positions[3 * (size_t)m.indices[3 * (size_t)f] + k];
-                        float b = m.positions[3 * (size_t)m.indices[3 * (size_t)f + 1] + k];
-                        float c = m.positions[3 * (size_t)m.indices[3 * (size_t)f + 2] + k];
-                        lo[3 * (size_t)f + k] = std::min(a, std::min(b, c));
-                        hi[3 * (size_t)f + k] = std::max(a, std::max(b, c));
-                    }
-                built_ok[mi] = rr::build_bvh(lo.data(), hi.data(), nt, RR_MAX_LEAF_TRIS, s->blas_depth_limit, &built[mi]) ? 1 : 0;
-            }
-        };
-        const unsigned hw = std::thread::hardware_concurrency();
-        const uint32_t n_threads = std::min<uint32_t>(std::min<uint32_t>(hw ? hw : 4u, 16u), std::max<uint32_t>(fs->n_meshes, 1u));
-        std::vector<std::thread> pool;
-        for (uint32_t t = 1; t < n_threads; t++) pool.emplace_back(worker);
-        worker();
-        for (std::thread& t : pool) t.join();
-    }
+    build_mesh_trees(fs, s->blas_depth_limit, &built, &built_ok);
     for (uint32_t mi = 0; mi < fs->n_meshes; mi++) {
         const rr_mesh& m = fs->meshes[mi];
         uint32_t nt = m.n_triangles;
@@ -877,19 +972,22 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     HIP_TRY(hipHostMalloc((void**)&s->h_count, 64, hipHostMallocDefault));
     *out = s.release();
     return RR_OK;
-}
+} RR_GUARD_END("rr_scene_create")
 
 extern "C" void rr_scene_destroy(rr_scene* s) {
     if (!s) return;
-    (void)hipSetDevice(s->device);
-    (void)hipDeviceSynchronize();
-    delete s; // ~rr_scene: events, pinned memory; ~DevBuf: every device buffer
+    try {
+        (void)hipSetDevice(s->device);
+        (void)hipDeviceSynchronize();
+        delete s; // ~rr_scene: events, pinned memory; ~DevBuf: every device buffer
+    } catch (...) { (void)guard_fail("rr_scene_destroy"); }
 }
 
-extern "C" int rr_scene_update_transforms(rr_scene* s, const float* trans, const float* trans_inv) {
+extern "C" int rr_scene_update_transforms(rr_scene* s, const float* trans, const float* trans_inv) try {
     if (!s || !trans || !trans_inv) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
     std::lock_guard<std::mutex> lk(s->mu);
     HIP_TRY(hipSetDevice(s->device));
+    RR_FAULT_POINT("update_transforms.host");
     uint32_t n = (uint32_t)s->h_items.size();
     bool general_w = false;
     for (uint32_t i = 0; i < n; i++) {
@@ -915,12 +1013,12 @@ extern "C" int rr_scene_update_transforms(rr_scene* s, const float* trans, const
         s->view.tlas_root4 = root4;
     }
     return RR_OK;
-}
+} RR_GUARD_END("rr_scene_update_transforms")
 
 // Material edits between frames (GUI sliders: reference src/run.rs:1132-1133 writes through Material::apply_diff,
 // src/shape/mod.rs:182-242): every material record is replaced and the item flag words derived from the material
 // caches are rebuilt; geometry, acceleration structures and texture images stay as uploaded.
-extern "C" int rr_scene_update_materials(rr_scene* s, const rr_material* materials, uint32_t n_materials) {
+extern "C" int rr_scene_update_materials(rr_scene* s, const rr_material* materials, uint32_t n_materials) try {
     if (!s || !materials) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
     std::lock_guard<std::mutex> lk(s->mu);
     if (n_materials != s->n_materials) return fail(RR_ERR_INVALID_ARGUMENT, "%u materials, the scene was created with %u", n_materials, s->n_materials);
@@ -943,7 +1041,7 @@ extern "C" int rr_scene_update_materials(rr_scene* s, const rr_material* materia
     if (n_materials) HIP_TRY(hipMemcpy(s->materials.p, dmat.data(), dmat.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
     if (!s->h_items.empty()) HIP_TRY(hipMemcpy(s->items.p, s->h_items.data(), s->h_items.size() * sizeof(DItem), hipMemcpyHostToDevice));
     return RR_OK;
-}
+} RR_GUARD_END("rr_scene_update_materials")
 
 // ---------------------------------------------------------------------------
 // frame
@@ -1342,7 +1440,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
 }
 
 extern "C" int rr_render_region_device(rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy,
-                                       const rr_region* rg, const rr_frame* out, void* hip_stream, const volatile int* cancel) {
+                                       const rr_region* rg, const rr_frame* out, void* hip_stream, const volatile int* cancel) try {
     int rc = check_frame_args(s, cam, cfg, sample_xy);
     if (rc != RR_OK) return rc;
     rc = check_region(cam->width, cam->height, rg);
@@ -1350,7 +1448,7 @@ extern "C" int rr_render_region_device(rr_scene* s, const rr_camera* cam, const 
     if (!out || !out->rgba8) return fail(RR_ERR_INVALID_ARGUMENT, "out->rgba8 is required");
     std::lock_guard<std::mutex> lk(s->mu);
     return render_region_locked(s, cam, cfg, sample_xy, rg, out, false, (hipStream_t)hip_stream, cancel);
-}
+} RR_GUARD_END("rr_render_region_device")
 
 static int render_to_host(rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy, const rr_frame* out,
                           const volatile int* cancel, rr_pass_fn fn, void* user, uint32_t min_passes) {
@@ -1377,17 +1475,17 @@ static int render_to_host(rr_scene* s, const rr_camera* cam, const rr_config* cf
 }
 
 extern "C" int rr_render(rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy, const rr_frame* out,
-                         const volatile int* cancel) {
+                         const volatile int* cancel) try {
     return render_to_host(s, cam, cfg, sample_xy, out, cancel, nullptr, nullptr, 0);
-}
+} RR_GUARD_END("rr_render")
 
 extern "C" int rr_render_progressive(rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy, const rr_frame* out,
-                                     uint32_t min_passes, rr_pass_fn on_pass, void* user, const volatile int* cancel) {
+                                     uint32_t min_passes, rr_pass_fn on_pass, void* user, const volatile int* cancel) try {
     if (!on_pass) return fail(RR_ERR_INVALID_ARGUMENT, "on_pass is required (use rr_render for a one-shot frame)");
     return render_to_host(s, cam, cfg, sample_xy, out, cancel, on_pass, user, min_passes);
-}
+} RR_GUARD_END("rr_render_progressive")
 
-extern "C" int rr_scene_last_stats(const rr_scene* cs, rr_frame_stats* out) {
+extern "C" int rr_scene_last_stats(const rr_scene* cs, rr_frame_stats* out) try {
     if (!cs || !out) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
     rr_scene* s = const_cast<rr_scene*>(cs);
     std::lock_guard<std::mutex> lk(s->mu);
@@ -1401,17 +1499,17 @@ extern "C" int rr_scene_last_stats(const rr_scene* cs, rr_frame_stats* out) {
     s->stats.shadow_rays = c[RR_CNT_SHADOW]; s->stats.shaded_hits = c[RR_CNT_SHADED];
     *out = s->stats;
     return RR_OK;
-}
+} RR_GUARD_END("rr_scene_last_stats")
 
-extern "C" int rr_scene_set_compat(rr_scene* s, uint32_t flags) {
+extern "C" int rr_scene_set_compat(rr_scene* s, uint32_t flags) try {
     if (!s) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
     if (flags & ~RR_COMPAT_OCCLUDER_ALPHA_SHADOWS) return fail(RR_ERR_INVALID_ARGUMENT, "unknown compatibility flags 0x%x", flags);
     std::lock_guard<std::mutex> lk(s->mu);
     s->view.compat = (s->view.compat & RR_VIEW_NAN_BALLS) | flags; // the scene view is passed to the kernels by value with every launch
     return RR_OK;
-}
+} RR_GUARD_END("rr_scene_set_compat")
 
-extern "C" int rr_scene_set_tuning(rr_scene* s, const rr_tuning* t) {
+extern "C" int rr_scene_set_tuning(rr_scene* s, const rr_tuning* t) try {
     if (!s || !t) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
     if (t->struct_size != sizeof(rr_tuning)) return fail(RR_ERR_INVALID_ARGUMENT, "rr_tuning::struct_size %u, library expects %zu", t->struct_size, sizeof(rr_tuning));
     if (t->sample_group > 64u || (t->sample_group & (t->sample_group - 1u))) return fail(RR_ERR_INVALID_ARGUMENT, "sample_group %u is not 0 or a power of two <= 64", t->sample_group);
@@ -1419,13 +1517,13 @@ extern "C" int rr_scene_set_tuning(rr_scene* s, const rr_tuning* t) {
     s->tuning = *t;
     s->profiling = t->kernel_timing != 0;
     return RR_OK;
-}
-extern "C" int rr_scene_get_tuning(const rr_scene* s, rr_tuning* t) {
+} RR_GUARD_END("rr_scene_set_tuning")
+extern "C" int rr_scene_get_tuning(const rr_scene* s, rr_tuning* t) try {
     if (!s || !t) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
     *t = s->tuning;
     t->struct_size = (uint32_t)sizeof(rr_tuning);
     return RR_OK;
-}
+} RR_GUARD_END("rr_scene_get_tuning")
 
 // ---------------------------------------------------------------------------
 // multi-GPU epilogue: compact per-rank buffers (concatenated in rank order) -> frame order
@@ -1435,7 +1533,7 @@ static std::mutex g_gather_mu;
 static std::vector<GatherMap*> g_gather_maps;
 
 extern "C" int rr_deinterleave_device(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t n_ranks,
-                                      uint32_t elem_bytes, const void* src, void* dst, int device, void* hip_stream) {
+                                      uint32_t elem_bytes, const void* src, void* dst, int device, void* hip_stream) try {
     rr_region probe{tile_w, tile_h, n_ranks, 0};
     int rc = check_region(width, height, &probe);
     if (rc != RR_OK) return rc;
@@ -1466,14 +1564,14 @@ extern "C" int rr_deinterleave_device(uint32_t width, uint32_t height, uint32_t 
                        gm->index.as<uint32_t>(), np, words, (const uint32_t*)src, (uint32_t*)dst);
     HIP_TRY(hipGetLastError());
     return RR_OK;
-}
+} RR_GUARD_END("rr_deinterleave_device")
 
 // The gathered packs of a multi-rank frame -> the four frame-order buffers, one launch (k_gather_packed).
 struct GatherMap2 { DevBuf rank, local; uint32_t w, h, tw, th, n; int device; };
 static std::vector<GatherMap2*> g_gather_maps2;
 extern "C" int rr_deinterleave_packed_device(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t n_ranks,
                                              const void* packs, uint64_t pack_stride, const uint64_t* section_offset, const uint32_t* elem_bytes,
-                                             void* const* dst, int device, void* hip_stream) {
+                                             void* const* dst, int device, void* hip_stream) try {
     rr_region probe{tile_w, tile_h, n_ranks, 0};
     int rc = check_region(width, height, &probe);
     if (rc != RR_OK) return rc;
@@ -1511,7 +1609,7 @@ extern "C" int rr_deinterleave_packed_device(uint32_t width, uint32_t height, ui
     hipLaunchKernelGGL(k_gather_packed, dim3((uint32_t)((total + RR_BLOCK - 1) / RR_BLOCK)), dim3(RR_BLOCK), 0, (hipStream_t)hip_stream, g);
     HIP_TRY(hipGetLastError());
     return RR_OK;
-}
+} RR_GUARD_END("rr_deinterleave_packed_device")
 
 // Lock order of a set of scene handles: by address (std::less is a total order on pointers).
 static std::vector<rr_scene*> multi_lock_order(rr_scene* const* scenes, uint32_t n) {
@@ -1520,13 +1618,13 @@ static std::vector<rr_scene*> multi_lock_order(rr_scene* const* scenes, uint32_t
     return v;
 }
 // test hook (tests/test_abi.py): the order in which rr_render_multi would lock `scenes`, as indices into the caller's array
-extern "C" int rr_multi_lock_order(rr_scene* const* scenes, uint32_t n_scenes, uint32_t* order_out) {
+extern "C" int rr_multi_lock_order(rr_scene* const* scenes, uint32_t n_scenes, uint32_t* order_out) try {
     if (!scenes || !order_out || n_scenes == 0) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
     const std::vector<rr_scene*> v = multi_lock_order(scenes, n_scenes);
     for (uint32_t k = 0; k < n_scenes; k++)
         for (uint32_t i = 0; i < n_scenes; i++) if (scenes[i] == v[k]) { order_out[k] = i; break; }
     return RR_OK;
-}
+} RR_GUARD_END("rr_multi_lock_order")
 
 // Peer access between two devices, both ways: checked once per ordered pair, enabled on first use.
 // false = no direct path (the caller stages through the host).  The same device counts as direct.
@@ -1566,7 +1664,7 @@ static bool ensure_peer_access(int a, int b) {
 // tests/test_gpu_multi.py puts several handles on device 0).
 // ---------------------------------------------------------------------------
 extern "C" int rr_render_multi(rr_scene* const* scenes, uint32_t n_scenes, const rr_camera* cam, const rr_config* cfg,
-                               const uint16_t* sample_xy, const rr_frame* out, const volatile int* cancel) {
+                               const uint16_t* sample_xy, const rr_frame* out, const volatile int* cancel) try {
     if (!scenes || n_scenes == 0) return fail(RR_ERR_INVALID_ARGUMENT, "no scenes");
     if (n_scenes > 64) return fail(RR_ERR_UNSUPPORTED, "%u scene handles", n_scenes);
     for (uint32_t i = 0; i < n_scenes; i++) {
@@ -1647,13 +1745,19 @@ extern "C" int rr_render_multi(rr_scene* const* scenes, uint32_t n_scenes, const
             HIP_TRY(hipStreamSynchronize(s->multi_stream));
             return RR_OK;
         };
-        rcs[i] = body();
-        if (rcs[i] != RR_OK) errs[i] = tl_error; // the message lives in the worker's thread-local slot
+        try { RR_FAULT_POINT("render_multi.worker"); rcs[i] = body(); }
+        catch (...) { rcs[i] = guard_fail("rr_render_multi (device worker)"); }
+        if (rcs[i] != RR_OK) { try { errs[i] = tl_error; } catch (...) { } } // the message lives in the worker's thread-local slot
     };
-    std::vector<std::thread> threads;
-    for (uint32_t i = 1; i < n_scenes; i++) threads.emplace_back(work, i);
-    work(0);
-    for (auto& t : threads) t.join();
+    {
+        Workers threads; // joined on every path out of this block
+        std::vector<char> inline_run(n_scenes, 0);
+        for (uint32_t i = 1; i < n_scenes; i++)
+            if (!threads.spawn([&work, i]() { work(i); })) inline_run[i] = 1;
+        work(0);
+        for (uint32_t i = 1; i < n_scenes; i++) if (inline_run[i]) work(i); // a thread that could not be started: its device waits for ours
+        threads.join_and_rethrow();
+    }
     const auto t_joined = std::chrono::steady_clock::now();
     for (uint32_t i = 0; i < n_scenes; i++)
         if (rcs[i] != RR_OK) return fail(rcs[i], "device slot %u: %s", i, errs[i].c_str());
@@ -1675,13 +1779,13 @@ extern "C" int rr_render_multi(rr_scene* const* scenes, uint32_t n_scenes, const
     s0->stats.multi_devices = n_scenes; s0->stats.multi_peer_links = n_peer; s0->stats.multi_staged_links = n_staged;
     s0->stats.ms_multi_exchange = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_joined).count();
     return RR_OK;
-}
+} RR_GUARD_END("rr_render_multi")
 
 // ---------------------------------------------------------------------------
 // post-processing (reference src/post_processing.rs:123-181)
 // ---------------------------------------------------------------------------
 extern "C" int rr_post_process_device(uint32_t width, uint32_t height, int cavity, int outline, const uint8_t* rgba_in,
-                                      const float* normal, const uint32_t* object_id, uint8_t* rgba_out, int device, void* hip_stream) {
+                                      const float* normal, const uint32_t* object_id, uint8_t* rgba_out, int device, void* hip_stream) try {
     if (width == 0 || height == 0) return fail(RR_ERR_INVALID_ARGUMENT, "bad frame size %ux%u", width, height);
     if (!rgba_in || !rgba_out || rgba_in == rgba_out) return fail(RR_ERR_INVALID_ARGUMENT, "rgba_in / rgba_out must be distinct non-NULL buffers");
     if ((cavity && !normal) || (outline && !object_id)) return fail(RR_ERR_INVALID_ARGUMENT, "cavity needs the normal buffer, outline the object-id buffer");
@@ -1691,10 +1795,10 @@ extern "C" int rr_post_process_device(uint32_t width, uint32_t height, int cavit
                        cavity ? 1u : 0u, outline ? 1u : 0u, (const uint32_t*)rgba_in, normal, object_id, (uint32_t*)rgba_out);
     HIP_TRY(hipGetLastError());
     return RR_OK;
-}
+} RR_GUARD_END("rr_post_process_device")
 
 extern "C" int rr_post_process(uint32_t width, uint32_t height, int cavity, int outline, const uint8_t* rgba_in, const float* normal,
-                               const uint32_t* object_id, uint8_t* rgba_out, int device) {
+                               const uint32_t* object_id, uint8_t* rgba_out, int device) try {
     if (width == 0 || height == 0) return fail(RR_ERR_INVALID_ARGUMENT, "bad frame size %ux%u", width, height);
     if (!rgba_in || !rgba_out) return fail(RR_ERR_INVALID_ARGUMENT, "NULL image");
     if ((cavity && !normal) || (outline && !object_id)) return fail(RR_ERR_INVALID_ARGUMENT, "cavity needs the normal buffer, outline the object-id buffer");
@@ -1714,12 +1818,12 @@ extern "C" int rr_post_process(uint32_t width, uint32_t height, int cavity, int 
     }
     in.release(); out.release(); nrm.release(); ids.release();
     return rc;
-}
+} RR_GUARD_END("rr_post_process")
 
 // ---------------------------------------------------------------------------
 // pick (reference src/raytracing.rs:237-273): pixel-centre ray, one closest-hit query
 // ---------------------------------------------------------------------------
-extern "C" int rr_pick(rr_scene* s, const rr_camera* cam, int x, int y, rr_pick_result* out) {
+extern "C" int rr_pick(rr_scene* s, const rr_camera* cam, int x, int y, rr_pick_result* out) try {
     if (!s || !cam || !out) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
     if (x < 0 || y < 0 || (uint32_t)x >= cam->width || (uint32_t)y >= cam->height) return fail(RR_ERR_INVALID_ARGUMENT, "pixel (%d,%d) outside %ux%u", x, y, cam->width, cam->height);
     std::lock_guard<std::mutex> lk(s->mu);
@@ -1758,19 +1862,20 @@ extern "C" int rr_pick(rr_scene* s, const rr_camera* cam, int x, int y, rr_pick_
         memcpy(&out->distance, &hit[0], 4);
     }
     return RR_OK;
-}
+} RR_GUARD_END("rr_pick")
 
 // ---------------------------------------------------------------------------
 // ray queries: Raytracing::trace for caller-supplied rays (the closest-hit kernel of the deeper levels on a queue that
 // the host fills), rr_pick generalised
 // ---------------------------------------------------------------------------
-extern "C" int rr_trace_rays(rr_scene* s, const float* origins, const float* directions, uint32_t n, uint32_t depth, rr_ray_hit* out) {
+extern "C" int rr_trace_rays(rr_scene* s, const float* origins, const float* directions, uint32_t n, uint32_t depth, rr_ray_hit* out) try {
     if (!s || (n && (!origins || !directions || !out))) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
     if (depth == 0 || depth > 255u) return fail(RR_ERR_INVALID_ARGUMENT, "depth %u (1 .. 255)", depth);
     if (n == 0) return RR_OK;
     if (n > 0x7fffff00u) return fail(RR_ERR_UNSUPPORTED, "%u rays in one call", n);
     std::lock_guard<std::mutex> lk(s->mu);
     HIP_TRY(hipSetDevice(s->device));
+    RR_FAULT_POINT("trace_rays.host");
     std::vector<float4> r0(n), r1(n);
     std::vector<uint2> r2(n);
     {
@@ -1821,13 +1926,13 @@ extern "C" int rr_trace_rays(rr_scene* s, const float* origins, const float* dir
         }
     }
     return RR_OK;
-}
+} RR_GUARD_END("rr_trace_rays")
 
 // ---------------------------------------------------------------------------
 // device arithmetic probe (tests/test_device_math.py): runs rr_math.h functions on the GPU
 // ---------------------------------------------------------------------------
 extern "C" int rr_math_probe(int op, const float* a, const float* b, const float* c, int n, float* out0, float* out1, float* out2,
-                             uint64_t seed, int device) {
+                             uint64_t seed, int device) try {
     if (n <= 0 || !a || !out0) return fail(RR_ERR_INVALID_ARGUMENT, "bad arguments");
     if (op == 11) { // the HOST build of the per-triangle shading constants (tri_shading_constants): a, b, c hold n / 3 triangles' vertices, xyz interleaved
         for (int t = 0; t + 2 < n; t += 3) {
@@ -1859,7 +1964,7 @@ extern "C" int rr_math_probe(int op, const float* a, const float* b, const float
         in[k].release(); o[k].release();
     }
     return RR_OK;
-}
+} RR_GUARD_END("rr_math_probe")
 
 #ifdef RR_EXP_UTIL
 extern "C" int rr_exp_util(unsigned long long* out64, int reset) {

@@ -138,3 +138,72 @@ def test_header_is_plain_c99_and_links(tmp_path):
                            "-L" + libdir, "-lrustray_hip", "-Wl,-rpath," + libdir])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "abi c99 OK" in out.stdout, out.stdout + out.stderr
+
+
+# ---- nothing unwinds across the ABI: exceptions on the calling thread and in host worker threads -------------
+def _host_build(fs, fault=None):
+    """rr_test_host_build = the host half of rr_scene_create (validation + threaded mesh tree builds), reachable without a GPU."""
+    L = capi.lib()
+    L.rr_test_fault.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    L.rr_test_host_build.argtypes = [C.POINTER(rr_flat_scene), C.POINTER(C.c_uint64)]
+    cs = fs.c_struct()
+    n = C.c_uint64(0)
+    if fault:
+        assert L.rr_test_fault(fault[0].encode(), fault[1], fault[2]) == 0
+    try:
+        rc = L.rr_test_host_build(C.byref(cs), C.byref(n))
+    finally:
+        L.rr_test_fault(b"", 0, 0)
+    return rc, n.value, L.rr_last_error().decode()
+
+
+def test_exceptions_do_not_cross_the_abi():
+    """The host is Rust with panic = "abort" (reference Cargo.toml:9-11): a C++ exception must come back as a status code.
+    std::bad_alloc -> RR_ERR_OUT_OF_MEMORY, any other exception -> RR_ERR_DEVICE with what() in rr_last_error(), on the calling
+    thread AND inside the worker threads that build the per-mesh trees (a worker that throws used to end in std::terminate)."""
+    fs = load_scene("kbert_room")   # several meshes: the tree builds run on several threads
+    assert len(fs.meshes) >= 4
+    rc, nodes, _ = _host_build(fs)
+    assert rc == 0 and nodes > 0
+    # calling thread
+    rc, _, msg = _host_build(fs, ("scene_create.host", 1, 0))
+    assert rc == -5 and "rr_test_host_build" in msg and "memory" in msg
+    rc, _, msg = _host_build(fs, ("scene_create.host", 2, 0))
+    assert rc == -4 and "injected fault at scene_create.host" in msg
+    rc, _, msg = _host_build(fs, ("scene_create.host", 3, 0))
+    assert rc == -4 and "unknown exception" in msg
+    # worker threads: the first mesh any worker picks up, and a later one (other workers are mid-build then)
+    for skip in (0, 2):
+        rc, _, msg = _host_build(fs, ("scene_create.mesh_worker", 1, skip))
+        assert rc == -5, (skip, rc, msg)
+        rc, _, msg = _host_build(fs, ("scene_create.mesh_worker", 2, skip))
+        assert rc == -4 and "injected fault" in msg, (skip, rc, msg)
+    # and the library still works afterwards (no thread left behind, no lock held)
+    rc, nodes2, _ = _host_build(fs)
+    assert rc == 0 and nodes2 == nodes
+
+
+def test_every_entry_point_is_guarded():
+    """Every `extern "C" int rr_*` definition in rr_api.hip is a function-try-block closed by RR_GUARD_END (the no-throw promise of
+    include/rustray_hip.h:21-23 is structural, not case by case)."""
+    src = open(os.path.join(ROOT, "rustray_amd", "csrc", "rr_api.hip")).read()
+    names = re.findall(r'extern "C" int (rr_[a-z_]+)\(', src)
+    assert len(names) >= 20
+    exempt = {"rr_test_fault", "rr_exp_util"}   # noexcept by construction (atomics and a strcpy) / developer build only
+    for n in names:
+        if n in exempt:
+            continue
+        assert re.search(r'extern "C" int ' + n + r'\([^{]*\) try \{', src), f"{n} is not a function-try-block"
+        assert f'RR_GUARD_END("{n}")' in src, f"{n} has no RR_GUARD_END"
+    assert "std::thread> pool" not in src and "threads.emplace_back(work" not in src   # worker threads only through `Workers`
+
+
+def test_guard_from_a_c_host(tmp_path):
+    """The same through a C program (no Python frames in between): a throwing worker must not terminate the process."""
+    import subprocess
+    exe = str(tmp_path / "guard_c99")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "native", "guard_c99.c"),
+                           "-L" + libdir, "-lrustray_hip", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "guard c99 OK" in out.stdout, out.stdout + out.stderr

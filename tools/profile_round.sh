@@ -1,17 +1,18 @@
 #!/bin/bash
 # Collects the judged evidence of a round on the GPU box: bench line, rocprofv3 kernel stats, and the PMC passes
 # (HBM traffic, SQ issue / wait counters, TCP counters), each PMC set in its own run with --kernel-trace only.
-# usage (through gpurun): tools/profile_round.sh <tag> [quick]     -> gpurun_out/<tag>/ ; then, back in the container:
-#        python tools/summarize_profiles.py <tag> <name>           -> profiles/<name>_*.{json,csv}
+# usage (through gpurun): tools/profile_round.sh <tag> [quick|full] [bench args]   -> gpurun_out/<tag>/ ; then, back in the container:
+#        python tools/summarize_profiles.py <tag> <name> [note] [scene]   -> profiles/<name>_*_<scene>.{json,csv}
 # "quick": SQ + kernel stats only (before / after comparisons of one kernel change).
-tag=$1; mode=$2
+# bench args select another workload, e.g.  tools/profile_round.sh r04_helmet full --scene helmet_syn --spp 64
+tag=$1; mode=$2; shift; shift
 R=${RR_CODE_ROOT:-$GRAFT_REPO_ROOT}   # the code (a frozen copy under tools/gpu.sh); output always goes to the real gpurun_out/
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-extras"
+B="python3 $R/bench.py --no-cpu-baseline --no-extras $*"
 if [ "$mode" != "quick" ]; then
-  python3 $R/bench.py > $out/bench_n1.json 2> $out/bench_n1.err || { echo "bench failed"; tail -5 $out/bench_n1.err; exit 1; }
+  python3 $R/bench.py "$@" > $out/bench_n1.json 2> $out/bench_n1.err || { echo "bench failed"; tail -5 $out/bench_n1.err; exit 1; }
 fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $B --steps 3 --warmup 1 > $out/stats_bench.json 2> $out/stats.err || { echo "stats pass failed"; exit 1; }
 pass() { # name, counters...

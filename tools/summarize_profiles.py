@@ -4,7 +4,7 @@
     <name>_hbm_traffic.json           FETCH_SIZE / WRITE_SIZE per kernel (separate passes, gfx950 correction applied)
     <name>_sq_counters.json           SQ instruction / wait counters per kernel + the derived issue fractions bench.py quotes
     <name>_tcp_counters.json          vector-L1 (TCP) and L2 (TCC) counters per kernel
-usage: python tools/summarize_profiles.py <tag> <name> [build note]   e.g. r02c r02"""
+usage: python tools/summarize_profiles.py <tag> <name> [build note] [scene]   e.g. r02c r02; scene (default sponza_syn) only names the files"""
 import collections
 import csv
 import glob
@@ -14,6 +14,8 @@ import shutil
 import sys
 
 tag, name = sys.argv[1], sys.argv[2]
+scene = sys.argv[4] if len(sys.argv) > 4 else "sponza_syn"
+sfx = "" if scene == "sponza_syn" else "_" + scene   # the headline workload keeps the names bench.py looks for
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 KERNELS = ("k_trace_closest", "k_trace_closest<true>", "k_trace_closest<false>", "k_trace_shadow", "k_trace_shadow<true>", "k_trace_shadow<false>", "k_shade", "k_shade<true>", "k_shade<false>", "k_resolve")
@@ -67,7 +69,7 @@ for cand in ("bench_n1.json", "stats_bench.json"):
     if os.path.exists(p) and os.path.getsize(p) > 0:
         bench = json.loads(open(p).read().strip().splitlines()[-1])
         if cand == "bench_n1.json":
-            shutil.copy(p, f"profiles/{name}_bench_sponza_syn_n1.json")
+            shutil.copy(p, f"profiles/{name}_bench_{scene}_n1.json")
         break
 workload = bench["config"]["workload"] if bench else "?"
 rays_closest = (bench["rays_per_frame"]["primary"] + bench["rays_per_frame"]["secondary"]) if bench else None
@@ -76,7 +78,7 @@ rays_shadow = bench["rays_per_frame"]["shadow"] if bench else None
 stats = newest(os.path.join("stats", "**", "*_kernel_stats.csv"))
 kernel_ns = {}
 if stats:
-    shutil.copy(stats, f"profiles/{name}_kernel_stats_sponza_syn.csv")
+    shutil.copy(stats, f"profiles/{name}_kernel_stats_{scene}.csv")
     for r in csv.DictReader(open(stats)):
         kernel_ns[kname(r["Name"])] = dict(calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), total_ns=float(r["TotalDurationNs"]))
     with_totals(kernel_ns, lambda parts: dict(calls=sum(p["calls"] for p in parts), total_ns=sum(p["total_ns"] for p in parts),
@@ -98,7 +100,7 @@ if fetch and write:
         out["kernels"][k] = {"launches_per_frame": n, "FETCH_SIZE_raw_bytes_per_frame": fr, "WRITE_SIZE_bytes_per_frame": wr,
                              "hbm_bytes_per_launch_corrected": (2 * fr + wr) / max(n, 1)}
     out["k_trace_closest_bytes_per_launch"] = out["kernels"]["k_trace_closest"]["hbm_bytes_per_launch_corrected"]
-    json.dump(out, open(f"profiles/{name}_hbm_traffic.json", "w"), indent=1)
+    json.dump(out, open(f"profiles/{name}_hbm_traffic{sfx}.json", "w"), indent=1)
 
 # ---- SQ counters
 sq = collections.defaultdict(dict)
@@ -113,7 +115,7 @@ if sq:
            "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_INSTS_* count wave-instructions; SQ_BUSY_CYCLES is summed over the shader engines",
            "valu_issue_peak": f"{N_SIMD} SIMD-32 x {CLOCK_GHZ} GHz / 2 cycles per wave64 VALU instruction = {N_SIMD * CLOCK_GHZ / 2:.1f} G wave-inst/s",
            "source_id": (bench or {}).get("source_id"),   # rustray_amd.capi.source_id() of the build that was profiled: bench.py quotes valu_insts_per_ray only for the same sources
-           "build_note": sys.argv[3] if len(sys.argv) > 3 else "the shipped build (rustray_amd/csrc/Makefile flags)",
+           "build_note": sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] else "the shipped build (rustray_amd/csrc/Makefile flags)",
            "frame_checksum": (bench or {}).get("frame_checksum"),
            "kernels": {}}
     for k in KERNELS:
@@ -122,7 +124,9 @@ if sq:
         d = dict(sq[k])
         rays = {"k_trace_closest": rays_closest, "k_trace_shadow": rays_shadow,
                 "k_trace_closest<true>": bench["rays_per_frame"]["primary"] if bench else None,
-                "k_trace_closest<false>": bench["rays_per_frame"]["secondary"] if bench else None}.get(k)
+                "k_trace_closest<false>": bench["rays_per_frame"]["secondary"] if bench else None,
+                "k_trace_shadow<true>": (bench or {}).get("rays_per_frame", {}).get("shadow_level1"),
+                "k_trace_shadow<false>": (bench or {}).get("rays_per_frame", {}).get("shadow_deeper")}.get(k)
         if rays and "SQ_INSTS_VALU" in d:
             d["rays_per_frame"] = rays
             d["valu_insts_per_ray"] = d["SQ_INSTS_VALU"] / rays
@@ -139,7 +143,7 @@ if sq:
         if "SQ_THREAD_CYCLES_VALU" in d and "SQ_ACTIVE_INST_VALU" in d and d["SQ_ACTIVE_INST_VALU"]:
             d["avg_active_lanes_per_valu"] = d["SQ_THREAD_CYCLES_VALU"] / d["SQ_ACTIVE_INST_VALU"]  # of 64
         out["kernels"][k] = d
-    json.dump(out, open(f"profiles/{name}_sq_counters.json", "w"), indent=1)
+    json.dump(out, open(f"profiles/{name}_sq_counters{sfx}.json", "w"), indent=1)
 
 # ---- TCP / TCC / GRBM counters
 tc = collections.defaultdict(dict)
@@ -162,5 +166,5 @@ if tc:
         if d.get("GRBM_GUI_ACTIVE") and k in kernel_ns:
             d["effective_clock_ghz"] = d["GRBM_GUI_ACTIVE"] / 8.0 / (kernel_ns[k]["total_ns"] / 4.0)
         out["kernels"][k] = d
-    json.dump(out, open(f"profiles/{name}_tcp_counters.json", "w"), indent=1)
+    json.dump(out, open(f"profiles/{name}_tcp_counters{sfx}.json", "w"), indent=1)
 print("wrote", sorted(glob.glob(f"profiles/{name}_*")))
