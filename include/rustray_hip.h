@@ -62,6 +62,19 @@ typedef enum rr_status {
 #define RR_MAX_SAMPLES_WITH_TABLE 32766u
 #define RR_MAX_SAMPLES 16382u
 
+/* Largest number of scene items (the reference has none: `items: Vec<..>`, src/scene.rs:69-83).  The top level of the acceleration
+ * structure holds one item per leaf and shares a fixed traversal stack (39 entries per ray, in LDS) with the per-mesh trees: up to
+ * 4 096 items it takes 12 levels of it, beyond that ceil(log2 n_items), which leaves 36 - ceil(log2 n_items) levels -- at least 16:
+ * 524 288 triangles in any ONE mesh at worst, 134 M with up to 4 096 items -- to a mesh's own tree.  rr_scene_create answers
+ * RR_ERR_UNSUPPORTED beyond either bound.  Scenes of 17 .. 512 items additionally get the packet form of the top level (coherent
+ * packets test the items' boxes with one item per lane instead of walking the tree per ray); outside that range every ray walks
+ * the tree -- same frame, bit for bit, at more node steps per ray.
+ * Memory per INSTANCE of a mesh: a 208-B item record plus 32 B per triangle of the mesh (the world normals of its flat-shaded hits,
+ * both signs, evaluated once per instanced triangle instead of per hit); the mesh itself -- vertices, attributes, tree: about 230 B
+ * per triangle -- is shared by its instances.  The sum over all items of their meshes' triangle counts is limited to 2^31 (64 GB of
+ * such normals): RR_ERR_UNSUPPORTED beyond. */
+#define RR_MAX_ITEMS 1048576u
+
 /* TextureType order of reference src/shape/mod.rs:633-643. */
 enum {
     RR_TEX_BASE = 0,

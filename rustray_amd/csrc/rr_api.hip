@@ -157,8 +157,10 @@ struct rr_scene {
     std::vector<DItem> h_items;
     std::vector<uint32_t> h_slot_face; // per mesh triangle: leaf-order slot -> original face index (rr_trace_rays reports the reference's face id)
     std::vector<ItemHost> item_host; // what rr_scene_update_materials needs to rebuild the item flag words
-    // the vertex positions of every mesh (xyz; empty: more than RR_TIGHT_BOX_MAX_VERTICES of them, or a non-finite one), for the items' world boxes
-    std::vector<std::vector<float>> mesh_points;
+    // per item: the extent of its surface along the rows of its transform (k_item_spans: minima, maxima, largest |local coordinate|; 9 doubles),
+    // read back after every upload of the items' transforms; the top level's surface boxes are derived from it (exact_world_box)
+    std::vector<double> h_spans;
+    DevBuf spans;
     std::vector<uint32_t> tex_width;
     std::vector<DTexture> h_textures; // descriptors of the uploaded images (copied into the material records, make_dmaterial)
     uint32_t n_materials = 0;
@@ -477,10 +479,10 @@ static void fill_item_matrices(DItem& d, const float* trans, const float* inv) {
 // NOT for balls: ray_ball has no box in front of it, and where its arithmetic overflows (a tiny ball: local coordinates
 // ~1e12) it answers Some(NaN) for ANY ray that passes the local box -- tests/golden/fuzz_568 holds such a scene -- so a ball
 // keeps the box of its local box's corners.  Not for a mesh whose tree is a single leaf either (nothing is culled in front of
-// its triangles).  `points`: the mesh's vertex positions, or NULL.
-#define RR_TIGHT_BOX_MAX_VERTICES 262144u
+// its triangles).  The extent of the vertices along the transform's rows comes from the device (k_item_spans), where the triangles live.
 struct WorldBox { double lo[3], hi[3]; bool tight[3]; double ext[3]; }; // tight[r]: axis r comes from the vertices; ext: largest |local coordinate| per local axis
-static WorldBox exact_world_box(const DItem& it, const std::vector<float>* points) {
+// `span`: the 9 doubles k_item_spans wrote for this item (extent of the mesh's vertices along the transform's rows), or NULL = corners only
+static WorldBox exact_world_box(const DItem& it, const double* span) {
     WorldBox b;
     const float4 rows[3] = {it.tr0, it.tr1, it.tr2};
     for (int r = 0; r < 3; r++) { b.lo[r] = 1e300; b.hi[r] = -1e300; b.tight[r] = false; b.ext[r] = 0.0; }
@@ -491,22 +493,17 @@ static WorldBox exact_world_box(const DItem& it, const std::vector<float>* point
             b.lo[r] = std::min(b.lo[r], v); b.hi[r] = std::max(b.hi[r], v);
         }
     }
-    if (!(it.flags & RR_IF_SPHERE) && it.root4 >= 0 && points && !points->empty()) {
-        const float* p = points->data();
-        const size_t n = points->size() / 3;
-        double* ext = b.ext; // largest |coordinate| per local axis: what the leaf padding is relative to
-        for (size_t i = 0; i < n; i++)
-            for (int c = 0; c < 3; c++) ext[c] = std::max(ext[c], std::fabs((double)p[3 * i + c]));
-        for (int r = 0; r < 3; r++) {
-            const double mx = rows[r].x, my = rows[r].y, mz = rows[r].z;
-            double lo = 1e300, hi = -1e300;
-            for (size_t i = 0; i < n; i++) {
-                const double v = mx * p[3 * i] + my * p[3 * i + 1] + mz * p[3 * i + 2];
-                lo = std::min(lo, v); hi = std::max(hi, v);
+    if (!(it.flags & RR_IF_SPHERE) && it.root4 >= 0 && span) {
+        bool finite = true;
+        for (int k = 0; k < 9; k++) finite = finite && std::isfinite(span[k]);
+        if (finite) {
+            for (int c = 0; c < 3; c++) b.ext[c] = span[6 + c]; // what the leaf padding is relative to
+            for (int r = 0; r < 3; r++) {
+                const double mx = rows[r].x, my = rows[r].y, mz = rows[r].z;
+                const double leaf_pad = 2.0e-5 * (std::fabs(mx) * b.ext[0] + std::fabs(my) * b.ext[1] + std::fabs(mz) * b.ext[2]) + 1e-30;
+                const double tlo = span[r] + (double)rows[r].w - leaf_pad, thi = span[3 + r] + (double)rows[r].w + leaf_pad;
+                if (std::isfinite(tlo) && std::isfinite(thi) && tlo <= thi && (tlo > b.lo[r] || thi < b.hi[r])) { b.lo[r] = std::max(b.lo[r], tlo); b.hi[r] = std::min(b.hi[r], thi); b.tight[r] = true; }
             }
-            const double leaf_pad = 2.0e-5 * (std::fabs(mx) * ext[0] + std::fabs(my) * ext[1] + std::fabs(mz) * ext[2]) + 1e-30;
-            const double tlo = lo + (double)rows[r].w - leaf_pad, thi = hi + (double)rows[r].w + leaf_pad;
-            if (std::isfinite(tlo) && std::isfinite(thi) && tlo <= thi && (tlo > b.lo[r] || thi < b.hi[r])) { b.lo[r] = std::max(b.lo[r], tlo); b.hi[r] = std::min(b.hi[r], thi); b.tight[r] = true; }
         }
     }
     return b;
@@ -559,9 +556,8 @@ static int build_tlas(rr_scene* s, const double want_reach[3], std::vector<DNode
     // there an item matters through its nearest hit alone, and that lies in the tighter box
     std::vector<WorldBox> exact(n), surf(n);
     for (uint32_t i = 0; i < n; i++) {
-        const int32_t mesh = i < s->item_host.size() ? s->item_host[i].mesh : -1;
         exact[i] = exact_world_box(s->h_items[i], nullptr);
-        surf[i] = exact_world_box(s->h_items[i], (mesh >= 0 && (size_t)mesh < s->mesh_points.size()) ? &s->mesh_points[(size_t)mesh] : nullptr);
+        surf[i] = exact_world_box(s->h_items[i], s->h_spans.size() == 9 * (size_t)n ? &s->h_spans[9 * (size_t)i] : nullptr);
         for (int c = 0; c < 3; c++) {
             const double m = std::max(std::fabs(exact[i].lo[c]), std::fabs(exact[i].hi[c])) * 1.001 + 0.01; // + the shadow bias along the normal
             if (std::isfinite(m)) s->tlas_reach[c] = std::max(s->tlas_reach[c], m);
@@ -597,7 +593,7 @@ static int build_tlas(rr_scene* s, const double want_reach[3], std::vector<DNode
     }
     rr::BvhResult r;
     if (!rr::build_bvh(lo.data(), hi.data(), n, 1, s->tlas_depth_limit, &r))
-        return fail(RR_ERR_UNSUPPORTED, "scene has too many items (%u) for the top-level depth limit", n);
+        return fail(RR_ERR_UNSUPPORTED, "internal: top level over %u items does not fit %d levels", n, s->tlas_depth_limit);
     // leaves must name item indices directly: leaf order is a permutation, so re-code each 1-item leaf
     for (DNode& nd : r.nodes) {
         int32_t c[2];
@@ -654,12 +650,19 @@ static void camera_reach(const rr_camera* cam, const rr_config* cfg, double need
 }
 
 // DSceneView::flat_normals from the items and triangles on the device (k_world_normals); after every upload of the items' transforms
-static int update_flat_normals(rr_scene* s) {
+// ... and the extent of every item's surface along its transform's rows (k_item_spans -> s->h_spans, for the top level's surface boxes).
+// Everything that depends on the transforms and on the meshes is derived HERE, on the device, where the meshes are resident: the one
+// blocking copy of 72 B per item at the end is the call's only wait.
+static int derive_from_transforms(rr_scene* s) {
     const uint32_t n = (uint32_t)s->h_items.size();
+    s->h_spans.clear();
     if (n == 0) return RR_OK;
+    HIP_TRY(s->spans.reserve(9 * sizeof(double) * (size_t)n));
     hipLaunchKernelGGL(k_world_normals, dim3(n), dim3(RR_BLOCK), 0, nullptr, s->items.as<DItem>(), n, s->tris.as<DTri>(), s->flat_normals.as<float4>());
+    hipLaunchKernelGGL(k_item_spans, dim3(n), dim3(RR_BLOCK), 0, nullptr, s->items.as<DItem>(), n, s->tris.as<DTri>(), s->spans.as<double>());
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
+    s->h_spans.resize(9 * (size_t)n);
+    HIP_TRY(hipMemcpy(s->h_spans.data(), s->spans.p, 9 * sizeof(double) * (size_t)n, hipMemcpyDeviceToHost)); // (waits for both kernels)
     return RR_OK;
 }
 
@@ -796,6 +799,15 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     // than n - 1 pending entries, so a scene of few items leaves more levels to its per-mesh trees (a 320 k-triangle
     // mesh traces 3 % faster with 30 levels than with 24, and 7 % slower with 20)
     s->tlas_depth_limit = (int)std::min<uint32_t>(RR_TLAS_MAX_DEPTH, std::max<uint32_t>(1u, fs->n_items > 1 ? fs->n_items - 1 : 1u));
+    // More than 2^RR_TLAS_MAX_DEPTH items (the reference has no limit: `items: Vec<..>`, src/scene.rs:69-83): the top level takes the
+    // levels it needs -- ceil(log2 n): the builder falls back to object-median splits where the budget gets tight -- out of the
+    // per-mesh trees' share, down to 16 levels for those (8 * 2^16 triangles per mesh at worst); RR_MAX_ITEMS = 2^20 is where that ends.
+    if (fs->n_items > (1u << RR_TLAS_MAX_DEPTH)) {
+        if (fs->n_items > RR_MAX_ITEMS) return fail(RR_ERR_UNSUPPORTED, "%u items (RR_MAX_ITEMS = %u)", fs->n_items, RR_MAX_ITEMS);
+        int need = RR_TLAS_MAX_DEPTH;
+        while ((1u << need) < fs->n_items) need++;
+        s->tlas_depth_limit = need;
+    }
     s->blas_depth_limit = RR_STACK_DEPTH - 3 - s->tlas_depth_limit;
     // ---- meshes: one BLAS per mesh, shared by every item that names it
     struct MeshDev { uint32_t tri_base, n_tris; uint32_t node_base4; int32_t root4; bool has_normals, degenerate; };
@@ -813,7 +825,8 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     for (uint32_t mi = 0; mi < fs->n_meshes; mi++) {
         const rr_mesh& m = fs->meshes[mi];
         uint32_t nt = m.n_triangles;
-        if (!built_ok[mi]) return fail(RR_ERR_UNSUPPORTED, "mesh %u: BVH depth limit exceeded", mi);
+        if (!built_ok[mi]) return fail(RR_ERR_UNSUPPORTED, "mesh %u: %u triangles need a deeper tree than the %d levels left beside a top level over %u items",
+                                       mi, nt, s->blas_depth_limit, fs->n_items);
         rr::BvhResult& r = built[mi];
         md[mi].tri_base = (uint32_t)all_tris.size();
         md[mi].n_tris = nt;
@@ -878,15 +891,6 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         }
     }
 
-    s->mesh_points.assign(fs->n_meshes, std::vector<float>());
-    for (uint32_t mi = 0; mi < fs->n_meshes; mi++) {
-        const rr_mesh& m = fs->meshes[mi];
-        if (m.n_vertices == 0u || m.n_vertices > RR_TIGHT_BOX_MAX_VERTICES) continue;
-        bool finite = true;
-        for (size_t k = 0; k < 3 * (size_t)m.n_vertices && finite; k++) finite = std::isfinite(m.positions[k]);
-        if (finite) s->mesh_points[mi].assign(m.positions, m.positions + 3 * (size_t)m.n_vertices);
-    }
-
     // ---- items
     s->h_items.resize(fs->n_items);
     s->item_host.resize(fs->n_items);
@@ -920,6 +924,24 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         if (f & RR_IF_OCCLUDER_ALPHA_TEX) s->view.any_alpha_occluder = 1u;
     }
 
+    auto upload = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = b.reserve(std::max<size_t>(bytes, 16));
+        if (e != hipSuccess) return e;
+        return bytes ? hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    };
+    if (all_nodes4.size() >= (1u << 25)) return fail(RR_ERR_UNSUPPORTED, "%zu BVH4 nodes (nodes are addressed with 32-bit byte offsets)", all_nodes4.size());
+    HIP_TRY(upload(s->nodes4, all_nodes4.data(), all_nodes4.size() * sizeof(DNode4)));
+    HIP_TRY(upload(s->tris, all_tris.data(), all_tris.size() * sizeof(DTri)));
+    if (all_trix.size() >= (1u << 26)) return fail(RR_ERR_UNSUPPORTED, "%zu triangles (addressed with 32-bit byte offsets)", all_trix.size());
+    static_assert(sizeof(DTriX) == 48 && sizeof(DNode4) == 128 && sizeof(DMaterial) == 240, "layouts the kernels address by byte offset");
+    HIP_TRY(upload(s->trix, all_trix.data(), all_trix.size() * sizeof(DTriX)));
+    HIP_TRY(upload(s->attrs, all_attrs.data(), all_attrs.size() * sizeof(DTriAttr)));
+    HIP_TRY(upload(s->face_slot, all_face_slot.data(), all_face_slot.size() * 4));
+    HIP_TRY(upload(s->items, s->h_items.data(), s->h_items.size() * sizeof(DItem)));
+    HIP_TRY(s->flat_normals.reserve(std::max<size_t>((size_t)n_flat_normals * sizeof(float4), 16)));
+    rc = derive_from_transforms(s.get()); // flat world normals; the extent of every item's surface, for the top level below
+    if (rc != RR_OK) return rc;
+
     // ---- top level: always present (even for one item), so the kernels have a single traversal path.
     // The reference's choice between "all items" and its scene BVH (src/raytracing.rs:434) only changes the
     // candidate set, never the result.
@@ -932,27 +954,9 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
         for (int c = 0; c < 3; c++) s->tlas_floor[c] = s->tlas_reach[c];
     }
     s->tlas_node_capacity = std::max<uint32_t>((uint32_t)tlas4.size(), fs->n_items ? fs->n_items : 1u); // room for rebuilds after transform updates
-
-    auto upload = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
-        hipError_t e = b.reserve(std::max<size_t>(bytes, 16));
-        if (e != hipSuccess) return e;
-        return bytes ? hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
-    };
-    if (all_nodes4.size() >= (1u << 25)) return fail(RR_ERR_UNSUPPORTED, "%zu BVH4 nodes (nodes are addressed with 32-bit byte offsets)", all_nodes4.size());
-    HIP_TRY(upload(s->nodes4, all_nodes4.data(), all_nodes4.size() * sizeof(DNode4)));
     tlas4.resize(std::max<size_t>(tlas4.size(), s->tlas_node_capacity));
     HIP_TRY(upload(s->tnodes4, tlas4.data(), tlas4.size() * sizeof(DNode4)));
     HIP_TRY(upload(s->item_boxes, s->h_item_boxes.data(), s->h_item_boxes.size() * sizeof(float4)));
-    HIP_TRY(upload(s->tris, all_tris.data(), all_tris.size() * sizeof(DTri)));
-    if (all_trix.size() >= (1u << 26)) return fail(RR_ERR_UNSUPPORTED, "%zu triangles (addressed with 32-bit byte offsets)", all_trix.size());
-    static_assert(sizeof(DTriX) == 48 && sizeof(DNode4) == 128 && sizeof(DMaterial) == 240, "layouts the kernels address by byte offset");
-    HIP_TRY(upload(s->trix, all_trix.data(), all_trix.size() * sizeof(DTriX)));
-    HIP_TRY(upload(s->attrs, all_attrs.data(), all_attrs.size() * sizeof(DTriAttr)));
-    HIP_TRY(upload(s->face_slot, all_face_slot.data(), all_face_slot.size() * 4));
-    HIP_TRY(upload(s->items, s->h_items.data(), s->h_items.size() * sizeof(DItem)));
-    HIP_TRY(s->flat_normals.reserve(std::max<size_t>((size_t)n_flat_normals * sizeof(float4), 16)));
-    rc = update_flat_normals(s.get());
-    if (rc != RR_OK) return rc;
 
     DSceneView& v = s->view;
     v.flat_normals = s->flat_normals.as<float4>();
@@ -996,9 +1000,9 @@ extern "C" int rr_scene_update_transforms(rr_scene* s, const float* trans, const
         fill_item_matrices(s->h_items[i], t, ti);
         if (!(ti[3] == 0.0f && ti[7] == 0.0f && ti[11] == 0.0f && ti[15] == 1.0f)) general_w = true;
     }
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(s->items.p, s->h_items.data(), n * sizeof(DItem), hipMemcpyHostToDevice));
-    { int rc = update_flat_normals(s); if (rc != RR_OK) return rc; }
+    HIP_TRY(hipDeviceSynchronize()); // no frame may be in flight on the records that change (a caller that renders asynchronously through rr_render_region_device)
+    HIP_TRY(hipMemcpyAsync(s->items.p, s->h_items.data(), n * sizeof(DItem), hipMemcpyHostToDevice, nullptr));
+    { int rc = derive_from_transforms(s); if (rc != RR_OK) return rc; }
     s->view.general_w = general_w ? 1u : 0u;
     {
         std::vector<DNode4> tlas4; int32_t root4 = 0;
@@ -1094,6 +1098,29 @@ struct PassHook {
     rr_pass_fn fn; void* user; uint32_t min_passes;
     void* host[4]; size_t bytes[4];
 };
+
+// The ONE place that launches the closest-hit kernel: the frame path (run_level), rr_pick and rr_trace_rays all come through here, so a
+// change to the kernel's arguments cannot leave one caller behind.  (Round 3, scratch run r3c50: a variant whose LEVEL-1 build stored
+// the primary rays through q.r0 / q.r1 aborted the process inside rr_pick -- rr_pick built its own argument list with those pointers
+// NULL, which is right for the kernel at HEAD, which never touches them, and was a write to address 16 * i for that variant.)
+// Every pointer the build in question may touch is checked here, on the host, before the launch; level 1 reads no ray records (the
+// rays are derived from their index), so its queue carries the hit records only.
+static int launch_trace_closest(rr_scene* s, bool primary, DRayQueue q, uint32_t* count, uint32_t* head, uint64_t n, const DShadeConst* kc,
+                                const uint32_t* slot_xy, const DPrimary& pr, unsigned long long* counters, hipStream_t st) {
+    if (!count || !head || !q.hit || !kc || !counters) return fail(RR_ERR_DEVICE, "internal: closest-hit launch with a NULL argument");
+    if (primary && (!slot_xy || !pr.sample_xy || pr.n != n)) return fail(RR_ERR_DEVICE, "internal: level-1 closest-hit launch without its ray table");
+    if (!primary && (!q.r0 || !q.r1 || !q.r2)) return fail(RR_ERR_DEVICE, "internal: closest-hit launch without ray records");
+    if (n == 0 || n > 0x7fffff00ull) return fail(RR_ERR_DEVICE, "internal: closest-hit launch of %llu rays", (unsigned long long)n);
+    const int grid = (int)std::min<uint64_t>((n + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)s->n_cus * RR_CLOSEST_WAVES);
+    if (primary) {
+        q.r0 = nullptr; q.r1 = nullptr; q.r2 = nullptr;
+        hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, q, count, head, kc, slot_xy, pr, counters);
+    } else {
+        hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, q, count, head, kc, slot_xy, pr, counters);
+    }
+    HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
 
 static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy,
                                 const rr_region* rg, const rr_frame* out, bool frame_layout, hipStream_t st, const volatile int* cancel,
@@ -1268,7 +1295,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
 
     uint32_t* pool = s->pool.as<uint32_t>();
     unsigned long long* counters = s->counters.as<unsigned long long>();
-    const int trace_grid = s->n_cus * RR_CLOSEST_WAVES, shadow_grid = s->n_cus * RR_SHADOW_WAVES; // RR_STACK_DEPTH KB of LDS stack per 256-thread workgroup
+    const int shadow_grid = s->n_cus * RR_SHADOW_WAVES; // RR_STACK_DEPTH KB of LDS stack per 256-thread workgroup
     const int shade_grid_max = s->n_cus * 2 * RR_SHADE_WAVES;
     const uint32_t L = s->n_enabled_lights;
 
@@ -1303,9 +1330,8 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
             uint32_t* head = words(1);
             if (!head) return fail(RR_ERR_UNSUPPORTED, "out of memory for the per-launch counters of a batch");
             ScopedTimer t(s, st, d == 1 ? 4 : 0);
-            const int grid = (int)std::min<uint64_t>((n + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)trace_grid);
-            if (d == 1) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, qin, count, head, s->shade_const.as<DShadeConst>(), s->region_xy.as<uint32_t>(), pr, counters);
-            else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(RR_BLOCK), 0, st, s->view, qin, count, head, s->shade_const.as<DShadeConst>(), s->region_xy.as<uint32_t>(), pr, counters);
+            const int rcl = launch_trace_closest(s, d == 1, qin, count, head, n, s->shade_const.as<DShadeConst>(), s->region_xy.as<uint32_t>(), pr, counters, st);
+            if (rcl != RR_OK) return rcl;
         }
         const bool spawns = d <= R; // the deepest level spawns nothing (k_shade: depth <= max_recursion)
         const uint64_t child_base = d == 1 ? 0 : base + n;
@@ -1851,8 +1877,8 @@ extern "C" int rr_pick(rr_scene* s, const rr_camera* cam, int x, int y, rr_pick_
     DShadeConst hc;
     hc.sc = s->view; hc.fr = fr;
     HIP_TRY(hipMemcpy(b + 256, &hc, sizeof hc, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_trace_closest<true>, dim3(1), dim3(RR_BLOCK), 0, nullptr, s->view, q, (uint32_t*)(b + 96), (uint32_t*)(b + 100), (const DShadeConst*)(b + 256),
-                       (const uint32_t*)b, pr, (unsigned long long*)(b + 128));
+    { const int rc = launch_trace_closest(s, true, q, (uint32_t*)(b + 96), (uint32_t*)(b + 100), 1, (const DShadeConst*)(b + 256), (const uint32_t*)b, pr, (unsigned long long*)(b + 128), nullptr);
+      if (rc != RR_OK) return rc; }
     uint32_t hit[4];
     HIP_TRY(hipMemcpy(hit, b + 64, 16, hipMemcpyDeviceToHost));
     scratch.release();
@@ -1895,20 +1921,23 @@ extern "C" int rr_trace_rays(rr_scene* s, const float* origins, const float* dir
     }
     DevBuf b0, b1, b2, bh, bc;
     HIP_TRY(b0.reserve((size_t)n * 16)); HIP_TRY(b1.reserve((size_t)n * 16)); HIP_TRY(b2.reserve((size_t)n * 8)); HIP_TRY(bh.reserve((size_t)n * 16));
-    HIP_TRY(bc.reserve(64));
+    HIP_TRY(bc.reserve(256 + sizeof(DShadeConst))); // [0] the level's size, [4] the fetch head, [128] work counters, [256] scene view + (empty) frame constants
     HIP_TRY(hipMemcpy(b0.p, r0.data(), (size_t)n * 16, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b1.p, r1.data(), (size_t)n * 16, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b2.p, r2.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-    uint32_t words[16] = {n, 0u}; // [0] the level's size, [1] the fetch head
+    uint32_t words[64] = {n, 0u};
     HIP_TRY(hipMemcpy(bc.p, words, sizeof words, hipMemcpyHostToDevice));
     DRayQueue q{b0.as<float4>(), b1.as<float4>(), b2.as<uint2>(), bh.as<uint4>()};
-    DFrame fr;
-    memset(&fr, 0, sizeof fr);
+    {
+        DShadeConst hc;
+        memset(&hc, 0, sizeof hc);
+        hc.sc = s->view;
+        HIP_TRY(hipMemcpy(bc.as<char>() + 256, &hc, sizeof hc, hipMemcpyHostToDevice));
+    }
     DPrimary pr{nullptr, 0ull, 0u, 1u};
-    const int grid = (int)std::min<uint64_t>(((uint64_t)n + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)s->n_cus * RR_CLOSEST_WAVES);
-    hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(RR_BLOCK), 0, nullptr, s->view, q, bc.as<uint32_t>(), bc.as<uint32_t>() + 1,
-                       (const DShadeConst*)nullptr, (const uint32_t*)nullptr, pr, (unsigned long long*)nullptr);
-    HIP_TRY(hipGetLastError());
+    { const int rc = launch_trace_closest(s, false, q, bc.as<uint32_t>(), bc.as<uint32_t>() + 1, n, (const DShadeConst*)(bc.as<char>() + 256), nullptr, pr,
+                                          (unsigned long long*)(bc.as<char>() + 128), nullptr);
+      if (rc != RR_OK) return rc; }
     std::vector<uint4> hits(n);
     HIP_TRY(hipMemcpy(hits.data(), bh.p, (size_t)n * 16, hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < n; i++) {

@@ -24,6 +24,7 @@
 
 #define RR_BLOCK 256
 #define RR_SQ_SHARDS 32 // sub-queues of the shadow queue, one append counter each
+#define RR_DEPTH_WIDE ((int)0x80000000) // k_shade: this lane's depth term does not fit its 32-bit sum (accum_depth_wide_merged)
 #define RR_FIXED_SLOT_LIGHTS 32u // level 1 keeps fixed shadow slots for up to this many enabled lights (one bit per light in k_shade's sq_wrote)
 #ifndef RR_SQ_STRIDE
 #define RR_SQ_STRIDE 16 // words between two append counters: 64 B apart (packed into one line they cost k_shade 13-20 %)
@@ -441,6 +442,60 @@ struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool foun
         }                                                                                                      \
     }
 #endif
+// The same with the NON-uniform leaves tested in ROUNDS (RR_LEAF_ROUNDS): a parked lane tests RR_LEAF_ROUNDS triangles of its leaf per
+// round and stays parked while triangles are left, instead of every lane looping over its whole leaf while the lanes with shorter
+// leaves idle (leaves hold 1 .. 8 triangles).  `pi`: the lane's next triangle within its parked leaf.
+#define RR_LEAF_CLOSEST_ROUND(leaf, pi)                                                                        \
+    {                                                                                                          \
+        const int uleaf_ = __builtin_amdgcn_readfirstlane(leaf);                                               \
+        const uint32_t utri_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)tri_base_);                       \
+        if (SCALAR_LEAVES && sr.uni && __ballot((leaf) != uleaf_ || tri_base_ != utri_ || (pi) != 0u) == 0ull) { \
+            const uint32_t ucode = (uint32_t)~uleaf_;                                                          \
+            const uint32_t ufirst = RR_LEAF_FIRST(ucode), ucount = RR_LEAF_COUNT(ucode);                       \
+            const uint32_t ubase = utri_ + ufirst;                                                             \
+            for (uint32_t i = 0; i < ucount; i += 2u) {                                                        \
+                RR_UTIL(3)                                                                                     \
+                const bool two_ = i + 1u < ucount;                                                             \
+                const uint32_t o0 = (ubase + i) * 48u, o1 = (ubase + i + (two_ ? 1u : 0u)) * 48u;              \
+                DTriX ta, tb;                                                                                  \
+                RR_TRI_FETCH(ta, o0) RR_TRI_FETCH(tb, o1)                                                      \
+                RR_TRI_CLOSEST(ta, ufirst + i)                                                                 \
+                if (two_) RR_TRI_CLOSEST(tb, ufirst + i + 1u)                                                  \
+            }                                                                                                  \
+            (leaf) = 0;                                                                                        \
+        } else {                                                                                               \
+            const uint32_t code = (uint32_t)~(leaf);                                                           \
+            const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);                           \
+            _Pragma("unroll") for (int r_ = 0; r_ < RR_LEAF_ROUNDS; r_++) {                                    \
+                if ((pi) < count) {                                                                            \
+                    RR_UTIL(3) RR_UTIL_UNI(3, tri_base_ + first + (pi), 0)                                     \
+                    const DTriX tr = tri_at(sc.trix, (tri_base_ + first + (pi)) * 48u);                        \
+                    RR_TRI_CLOSEST(tr, first + (pi))                                                           \
+                    (pi)++;                                                                                    \
+                }                                                                                              \
+            }                                                                                                  \
+            if ((pi) >= count) (leaf) = 0;                                                                     \
+        }                                                                                                      \
+    }
+#define RR_LEAF_ANY_ROUND(leaf, pi)                                                                            \
+    {                                                                                                          \
+        const uint32_t code = (uint32_t)~(leaf);                                                               \
+        const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);                               \
+        _Pragma("unroll") for (int r_ = 0; r_ < RR_LEAF_ROUNDS; r_++) {                                        \
+            if ((pi) < count) {                                                                                \
+                RR_UTIL(3) RR_UTIL_UNI(3, tri_base_ + first + (pi), 0)                                         \
+                const DTriX tr = tri_at(sc.trix, (tri_base_ + first + (pi)) * 48u);                            \
+                float t; uint32_t side;                                                                        \
+                if (ray_triangle(mk3(tr.t0.x, tr.t0.y, tr.t0.z), mk3(tr.t1.x, tr.t1.y, tr.t1.z),               \
+                                 mk3(tr.t1.w, tr.t2.x, tr.t2.y), ray, &t, &side)) {                            \
+                    any = true;                                                                                \
+                    if (t <= limit) within = true;                                                             \
+                }                                                                                              \
+                (pi)++;                                                                                        \
+            }                                                                                                  \
+        }                                                                                                      \
+        if ((pi) >= count) (leaf) = 0;                                                                         \
+    }
 #define RR_LEAF_ANY(leaf)                                                                                      \
     {                                                                                                          \
         const uint32_t code = (uint32_t)~(leaf);                                                               \
@@ -470,18 +525,28 @@ RR_DEV void blas_closest(const DSceneView& sc, const DItem& it, const LRay& ray,
     int cur = RR_BLAS_ROOT(it);
     RR_UTIL(4)
     int pend = 0; // parked leaf (leaf codes are negative), 0 = none
+#ifdef RR_LEAF_ROUNDS
+    uint32_t pi = 0u; // next triangle of the parked leaf
+#endif
     for (;;) {
         if (cur >= 0) {
             RR_BLAS_STEP(nodes, sr, fminf(gbound, best.t))
         } else if (pend == 0 && cur != RR_SENTINEL) {
             pend = cur; sp--; cur = STK(sp);
+#ifdef RR_LEAF_ROUNDS
+            pi = 0u;
+#endif
         }
         const unsigned long long can_walk = __ballot(cur >= 0 || (pend == 0 && cur != RR_SENTINEL));
         const unsigned long long parked = __ballot(pend != 0);
         if ((can_walk | parked) == 0ull) break; // every lane of this walk is done
         const unsigned long long alive = __ballot(cur != RR_SENTINEL || pend != 0);
         if (can_walk == 0ull || __popcll(parked) * RR_PEND_DEN >= __popcll(alive) * RR_PEND_NUM) {
+#ifdef RR_LEAF_ROUNDS
+            if (pend != 0) { RR_LEAF_CLOSEST_ROUND(pend, pi) }
+#else
             if (pend != 0) { RR_LEAF_CLOSEST(pend) pend = 0; }
+#endif
         }
     }
     *out = best;
@@ -501,11 +566,17 @@ RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, flo
     RR_UTIL(4)
     // until some hit is known every box matters; afterwards only boxes that can still hold a hit within the limit
     int pend = 0;
+#ifdef RR_LEAF_ROUNDS
+    uint32_t pi = 0u;
+#endif
     for (;;) {
         if (cur >= 0) {
             RR_BLAS_STEP_ANY(nodes, sr, any ? limit : RR_FLT_MAX)
         } else if (pend == 0 && cur != RR_SENTINEL) {
             pend = cur; sp--; cur = STK(sp);
+#ifdef RR_LEAF_ROUNDS
+            pi = 0u;
+#endif
         }
         const unsigned long long can_walk = __ballot(cur >= 0 || (pend == 0 && cur != RR_SENTINEL));
         const unsigned long long parked = __ballot(pend != 0);
@@ -513,9 +584,14 @@ RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, flo
         const unsigned long long alive = __ballot(cur != RR_SENTINEL || pend != 0);
         if (can_walk == 0ull || __popcll(parked) * RR_PEND_DEN >= __popcll(alive) * RR_PEND_NUM) {
             if (pend != 0) {
+#ifdef RR_LEAF_ROUNDS
+                RR_LEAF_ANY_ROUND(pend, pi)
+                if (within) { cur = RR_SENTINEL; pend = 0; } // decided: this lane stops walking
+#else
                 RR_LEAF_ANY(pend)
                 pend = 0;
                 if (within) cur = RR_SENTINEL; // decided: this lane stops walking
+#endif
             }
         }
     }
@@ -1403,6 +1479,14 @@ RR_DEV void accum_aux_merged(const DAccum& acc, uint32_t pix, int nx, int ny, in
     }
 }
 
+// Depth terms beyond the 32-bit lane sums (|depth * 2^16| >= 2^25: a root hit farther than 512 units -- a scene modelled in centimetres,
+// a far background), merged like everything else: round 3 sent each of them to its accumulator word as an atomic of its own, 64 lanes
+// of a level-1 packet to ONE word (the cliff accum_aux_merged's comment describes, for depth alone).  All 64 lanes.
+RR_DEV void accum_depth_wide_merged(const DAccum& acc, uint32_t pix, long long depth) {
+    unsigned long long v[1] = {(unsigned long long)depth};
+    if (wave_merge_runs<1>(pix, v) && acc.depth && v[0]) atomicAdd((unsigned long long*)acc.depth + pix, v[0]);
+}
+
 // Share of a launch's packets that is dealt to the waves round-robin, without an atomic (see k_trace_closest).
 #ifndef RR_STATIC_NUM
 #define RR_STATIC_NUM 1
@@ -1715,7 +1799,10 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
         // ---- aux outputs of the root node (:742-744, :400-402): summed per pixel below, with the wave's other root hits
         if (depth == 1u) {
             aux_pix = pix;
-            fix_add(aux_d, hit_dist, RR_DEPTH_SCALE, 1.0e9f, acc.depth, pix);
+            {   // (a term beyond the 32-bit lane sum is marked and taken in 64 bits with the wave's other wide terms, after the light loop)
+                const float dx = hit_dist * RR_DEPTH_SCALE;
+                aux_d = rr_abs(dx) < 33554432.0f ? __float2int_rn(dx) : RR_DEPTH_WIDE;
+            }
             fix_add(aux_nx, normal.x, RR_FIX_SCALE, RR_FIX_CLAMP, acc.normal, pix);
             fix_add(aux_ny, normal.y, RR_FIX_SCALE, RR_FIX_CLAMP, acc.normal ? acc.normal + acc.n : nullptr, pix);
             fix_add(aux_nz, normal.z, RR_FIX_SCALE, RR_FIX_CLAMP, acc.normal ? acc.normal + 2ull * acc.n : nullptr, pix);
@@ -1872,12 +1959,14 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
                 nf |= nonfinite_flags(cr, cg, cb);
                 fix_add(sum_r, cr, RR_FIX_SCALE, RR_FIX_CLAMP, acc.rgb, pix); fix_add(sum_g, cg, RR_FIX_SCALE, RR_FIX_CLAMP, acc.rgb + acc.n, pix);
                 fix_add(sum_b, cb, RR_FIX_SCALE, RR_FIX_CLAMP, acc.rgb + 2ull * acc.n, pix);
-                if ((lk & 31u) == 31u) { // (hundreds of unshadowed lights: the 32-bit sums are flushed before they can overflow)
-                    if (sum_r) atomicAdd((unsigned long long*)acc.rgb + pix, (unsigned long long)(long long)sum_r);
-                    if (sum_g) atomicAdd((unsigned long long*)acc.rgb + acc.n + pix, (unsigned long long)(long long)sum_g);
-                    if (sum_b) atomicAdd((unsigned long long*)acc.rgb + 2ull * acc.n + pix, (unsigned long long)(long long)sum_b);
-                    sum_r = sum_g = sum_b = 0;
-                }
+            }
+            // Hundreds of unshadowed lights: the 32-bit sums are flushed every 32 enabled lights, whether or not THIS light added a term
+            // (inside the branch above a light 31 or 63 with a zero term skipped its flush, and 96 terms can pass 2^31).
+            if (!(m.flags & RR_MF_RECEIVE_SHADOW) && (lk & 31u) == 31u) {
+                if (sum_r) atomicAdd((unsigned long long*)acc.rgb + pix, (unsigned long long)(long long)sum_r);
+                if (sum_g) atomicAdd((unsigned long long*)acc.rgb + acc.n + pix, (unsigned long long)(long long)sum_g);
+                if (sum_b) atomicAdd((unsigned long long*)acc.rgb + 2ull * acc.n + pix, (unsigned long long)(long long)sum_b);
+                sum_r = sum_g = sum_b = 0;
             }
             const uint32_t si = sq_fixed ? lk * sq_cap + sq_slot : sq_base + wave_alloc(sq_count, want_shadow, lane);
             if (want_shadow) {
@@ -1920,7 +2009,14 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
         }
         if (nf) atomicOr(&acc.flags[pix_of_nf], nf); // rare: a non-finite term
         accum_merged(acc, sum_pix, sum_r, sum_g, sum_b);
-        if ((acc.normal || acc.depth) && __ballot(aux_pix != 0xffffffffu) != 0ull) accum_aux_merged(acc, aux_pix, aux_nx, aux_ny, aux_nz, aux_d);
+        if ((acc.normal || acc.depth) && __ballot(aux_pix != 0xffffffffu) != 0ull) {
+            if (__ballot(aux_d == RR_DEPTH_WIDE) != 0ull) { // hits beyond 512 units: their depth terms in 64 bits, merged per pixel
+                long long wide = 0ll;
+                if (aux_d == RR_DEPTH_WIDE) { wide = to_fix(__uint_as_float(qin.hit[i].x), RR_DEPTH_SCALE, 1.0e9f); aux_d = 0; }
+                accum_depth_wide_merged(acc, wide != 0ll ? aux_pix : 0xffffffffu, wide);
+            }
+            accum_aux_merged(acc, aux_pix, aux_nx, aux_ny, aux_nz, aux_d);
+        }
         {
             // one allocation for all children of the workgroup iteration: per wave the reflection rays first, then the refraction rays
             const unsigned long long m_refl = __ballot(spawn_refl), m_refr = __ballot(spawn_refr);
@@ -1971,6 +2067,61 @@ __global__ __launch_bounds__(RR_BLOCK) void k_world_normals(const DItem* __restr
         const f3 p = to_world_normal(it, ng), m = to_world_normal(it, -ng);
         out[it.wn_base + 2u * slot] = make_float4(p.x, p.y, p.z, 0.0f);
         out[it.wn_base + 2u * slot + 1u] = make_float4(m.x, m.y, m.z, 0.0f);
+    }
+}
+
+// The extent of every mesh item's SURFACE along the rows of its transform (rr_api.hip: exact_world_box): one workgroup per item over
+// the vertices of the mesh's triangles, which are resident (DTri), in double -- per row r the minimum and maximum of
+// tr_r.x * p.x + tr_r.y * p.y + tr_r.z * p.z, and the largest |coordinate| per local axis.  Products and sums are IEEE binary64
+// without contraction and minimum / maximum are exact, so the host evaluation this replaces (one thread, every vertex of every
+// item, three passes: a transform update of sponza_syn spent its time there) gives the same numbers.  A non-finite vertex makes a
+// span non-finite; the host then keeps the box of the local box's corners for that item.
+// out[9 * item + (0..2)] = minima, (3..5) = maxima, (6..8) = largest |coordinate|; spheres and empty meshes: +inf / -inf / 0.
+__global__ __launch_bounds__(RR_BLOCK) void k_item_spans(const DItem* __restrict__ items, uint32_t n_items, const DTri* __restrict__ tris, double* __restrict__ out) {
+    if (blockIdx.x >= n_items) return;
+    const DItem& it = items[blockIdx.x];
+    const bool mesh = !(it.flags & RR_IF_SPHERE);
+    const double inf = __builtin_inf();
+    double lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf}, ext[3] = {0.0, 0.0, 0.0};
+    bool bad = false; // a NaN coordinate (minimum / maximum would drop it)
+    if (mesh) {
+        const double m[3][3] = {{(double)it.tr0.x, (double)it.tr0.y, (double)it.tr0.z}, {(double)it.tr1.x, (double)it.tr1.y, (double)it.tr1.z},
+                                {(double)it.tr2.x, (double)it.tr2.y, (double)it.tr2.z}};
+        for (uint32_t slot = threadIdx.x; slot < it.n_tris; slot += RR_BLOCK) {
+            const DTri& t = tris[it.tri_base + slot];
+            const float4 vs[3] = {t.v0, t.v1, t.v2};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const double p[3] = {(double)vs[k].x, (double)vs[k].y, (double)vs[k].z};
+                if (p[0] != p[0] || p[1] != p[1] || p[2] != p[2]) bad = true;
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    const double v = m[r][0] * p[0] + m[r][1] * p[1] + m[r][2] * p[2];
+                    lo[r] = fmin(lo[r], v); hi[r] = fmax(hi[r], v);
+                    ext[r] = fmax(ext[r], fabs(p[r]));
+                }
+            }
+        }
+    }
+    __shared__ double s_red[RR_BLOCK / RR_WAVE][9];
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    if (bad) s_bad = 1;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[r] = fmin(lo[r], __shfl_down(lo[r], off)); hi[r] = fmax(hi[r], __shfl_down(hi[r], off)); ext[r] = fmax(ext[r], __shfl_down(ext[r], off));
+        }
+    if ((threadIdx.x & (RR_WAVE - 1)) == 0)
+        for (int r = 0; r < 3; r++) { s_red[threadIdx.x / RR_WAVE][r] = lo[r]; s_red[threadIdx.x / RR_WAVE][3 + r] = hi[r]; s_red[threadIdx.x / RR_WAVE][6 + r] = ext[r]; }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const int k = (int)threadIdx.x;
+        double v = s_red[0][k];
+        for (int w = 1; w < RR_BLOCK / RR_WAVE; w++) v = k < 3 ? fmin(v, s_red[w][k]) : fmax(v, s_red[w][k]);
+        if (s_bad) v = __builtin_nan("");
+        out[9ull * blockIdx.x + k] = v;
     }
 }
 

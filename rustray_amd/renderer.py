@@ -282,7 +282,11 @@ class TiledFrame:
         """ONE collective per frame: every rank sends its pack (RGBA8 and whichever aux buffers were rendered, one byte
         buffer), rank 0 gathers them (backend "nccl" = RCCL over xGMI, device tensors; `via_cpu` stages through host
         memory for "gloo", which cannot gather device tensors) and de-interleaves each buffer into frame order.
-        With `parts` from `alloc()` nothing is allocated or packed here: the views ARE the pack's sections."""
+        With `parts` from `alloc()` nothing is allocated or packed here: the views ARE the pack's sections.
+
+        ALIASING (device-kernel path): the returned tensors are reshaped VIEWS of this object's persistent frame buffers; the next
+        `gather` overwrites them in place.  A caller that keeps a frame across calls -- to compare two consecutive frames, say --
+        must `.clone()` it first (comparing two returned dicts without a copy always compares a buffer with itself)."""
         import torch
         import torch.distributed as dist
         keys = list(parts.keys())
@@ -333,7 +337,10 @@ class TiledFrame:
 
 def render_region_torch(device_scene: capi.DeviceScene, cam, cfg, tf: TiledFrame, aux: bool = False, sample_xy=None, via_cpu: bool = False) -> dict:
     """Render this rank's tiles on torch's current stream, straight into the sections of the rank's persistent pack
-    buffer (TiledFrame.alloc): nothing is allocated per frame and `tf.gather` sends the pack as it is."""
+    buffer (TiledFrame.alloc): nothing is allocated per frame and `tf.gather` sends the pack as it is.
+
+    ALIASING: the returned tensors are VIEWS of that persistent pack; the next call renders over them.  `.clone()` what must outlive
+    the next frame."""
     import torch
     dev = torch.device("cuda", device_scene.device)
     parts = tf.alloc(dev, aux, via_cpu=via_cpu)

@@ -72,6 +72,29 @@ int main() {
                 }
             }
         }
+    // top levels over more items than 2^RR_TLAS_MAX_DEPTH (round 4: rr_scene_create gives them ceil(log2 n) levels, one item per leaf):
+    // clustered boxes, so that SAH alone would go deeper than the budget and the median fallback has to hold it
+    for (uint32_t n : {4097u, 5000u, 100000u}) {
+        std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
+        for (uint32_t i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++) {
+                const float c = (i % 7u == 0u ? 100.0f : 1.0f) * u(rng) + (k == 0 ? 0.001f * (float)i : 0.0f);
+                lo[3 * (size_t)i + k] = c - 0.05f; hi[3 * (size_t)i + k] = c + 0.05f;
+            }
+        int limit = 12;
+        while ((1u << limit) < n) limit++;
+        rr::BvhResult r;
+        CHECK(rr::build_bvh(lo.data(), hi.data(), n, 1, limit, &r));
+        CHECK(r.order.size() == n && r.depth <= limit);
+        std::vector<DNode4> n4; int pending = -1;
+        const int32_t root4 = rr::collapse_bvh4(r, limit, false, &n4, &pending);
+        CHECK(pending <= limit);
+        std::multiset<uint32_t> seen;
+        CHECK(walk4(n4, root4, &seen));
+        CHECK(seen.size() == n && std::set<uint32_t>(seen.begin(), seen.end()).size() == n);
+        rr::BvhResult small;
+        CHECK(!rr::build_bvh(lo.data(), hi.data(), n, 1, limit - 1, &small)); // one level less cannot hold them: what rr_scene_create must never ask for
+    }
     std::printf("bvh host test OK\n");
     return 0;
 }

@@ -207,3 +207,39 @@ def test_guard_from_a_c_host(tmp_path):
                            "-L" + libdir, "-lrustray_hip", "-Wl,-rpath," + libdir])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "guard c99 OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_every_declared_symbol_is_in_the_rust_block():
+    """INTEGRATION.md section 1 is the binding a maintainer would paste into src/hip_ffi.rs (no Rust toolchain here, so it cannot be
+    compiled): every function the header declares must appear in its `extern "C"` block, with the header's number of parameters."""
+    hdr = open(os.path.join(ROOT, "include", "rustray_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index('#[link(name = "rustray_hip")]'):]
+    block = block[:block.index("```")]
+    block = re.sub(r"//[^\n]*", "", block)
+    # the callback type of rr_render_progressive has parameters of its own: fold nested parentheses away before counting commas
+    def n_params(arglist):
+        depth, flat = 0, []
+        for ch in arglist:
+            if ch == "(":
+                depth += 1
+            elif ch == ")":
+                depth -= 1
+            elif depth == 0:
+                flat.append(ch)
+        t = "".join(flat).strip()
+        return 0 if t in ("", "void") else t.count(",") + 1
+    def arglist_after(text, pos):
+        depth, i = 1, pos
+        while depth:
+            depth += {"(": 1, ")": -1}.get(text[i], 0)
+            i += 1
+        return text[pos:i - 1]
+    for name in declared_functions():
+        m = re.search(r"\b" + name + r"\s*\(", hdr)
+        want = n_params(arglist_after(hdr, m.end()))
+        r = re.search(r"pub fn " + name + r"\s*\(", block)
+        assert r, f"{name} is declared in the header but missing from INTEGRATION.md's extern block"
+        got = n_params(arglist_after(block, r.end()))
+        assert got == want, f"{name}: header has {want} parameters, INTEGRATION.md {got}"

@@ -4,7 +4,7 @@ import pytest
 
 from rustray_amd.flat import FlatScene, Item, Light, Material, MeshData, make_config
 from rustray_amd.scene import Scene
-from tests.helpers import camera_for, compare_frames
+from tests.helpers import camera_for, compare_frames, load_scene
 from tests.test_gpu_parity import assert_parity
 
 pytestmark = pytest.mark.gpu
@@ -216,3 +216,48 @@ def test_zero_light_term_still_reaches_the_pixel_through_a_nan_uv_and_only_then(
         else:
             assert st["shadow_rays"] == 0 and ref["counters"]["rays_shadow"] > 0   # (D7) nothing to find: not traced
     assert white[True] > 50 and white[False] == 0, white
+
+
+def _scaled_world(fs, S):
+    """The same scene with the world S times larger (item transforms, lights, camera): hit distances scale by S, colours stay
+    (point-light falloff is I / (4 pi d): the intensity scales with S)."""
+    import copy
+    from rustray_amd.scene import inverse_affine
+    out = copy.deepcopy(fs)
+    sc = np.diag([S, S, S, 1.0]).astype(np.float32)
+    for it in out.items:
+        it.trans = (sc @ np.asarray(it.trans, np.float32)).astype(np.float32)
+        it.trans_inv = inverse_affine(it.trans)
+    for l in out.lights:
+        l.pos = tuple(float(v) * S for v in l.pos)
+        if l.light_type != 0:
+            l.intensity = float(l.intensity) * S
+    cam = dict(out.meta["camera"])
+    cam["eye_pos"] = [float(v) * S for v in cam["eye_pos"]]
+    cam["clipping_far"] = float(cam.get("clipping_far", 100.0)) * S
+    out.meta = dict(out.meta); out.meta["camera"] = cam
+    return out
+
+
+def test_depth_of_far_hits_is_merged_per_pixel(hip, oracle):
+    """a root hit farther than 512 units does not fit the 32-bit lane sum of the depth accumulator (depth * 2^16 >= 2^25)
+    and was added as one unmerged 64-bit atomic per lane -- 64 lanes of a level-1 packet to one word.  Such terms are now merged per
+    pixel in 64 bits (accum_depth_wide_merged).  spheres_room scaled 200 x (hit distances 600 .. 4000 units) against the oracle, and
+    timed against the unscaled scene: the far form must not cost more than a fraction of the frame."""
+    near = load_scene("spheres_room")
+    far = _scaled_world(near, 200.0)
+    cfg = make_config(samples=64, monte_carlo=True, seed=6, max_recursion=2)
+    cam_f = camera_for(far, 160, 96).c_struct()
+    with hip.DeviceScene(far, 0) as ds:
+        out = ds.render(cam_f, cfg)
+        assert float(np.nanmax(out["depth"])) > 512.0
+        ds.set_profiling(True)
+        ds.render(cam_f, cfg); t_far = ds.stats()["ms_shade"]
+    ref = oracle.render(far.c_struct(), cam_f, make_config(samples=64, monte_carlo=True, seed=6, max_recursion=2), n_threads=8)
+    res = compare_frames(out, ref)
+    assert res["n_rgb_over"] == 0 and res["n_id_diff"] == 0 and res["max_depth_rel"] < 1e-4, res
+    with hip.DeviceScene(near, 0) as ds:
+        ds.set_profiling(True)
+        cam_n = camera_for(near, 160, 96).c_struct()
+        ds.render(cam_n, cfg); ds.render(cam_n, cfg); t_near = ds.stats()["ms_shade"]
+    assert t_far < 1.5 * t_near + 0.2, (t_far, t_near)

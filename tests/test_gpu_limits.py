@@ -119,3 +119,79 @@ def test_bad_frame_arguments_come_back_as_codes(hip):
             ds.render(cam, make_config(samples=1))
         ok = ds.render(camera_for(fs, 16, 16).c_struct(), make_config(samples=1))   # the handle survives every rejected call
         assert ok["rgba"].shape == (16, 16, 4)
+
+
+def _many_items_scene(n_spheres, n_quads, seed=3):
+    """n_spheres small spheres + n_quads two-triangle meshes (all sharing ONE mesh: instancing) on a jittered grid over a floor."""
+    from rustray_amd.flat import FlatScene, Item, Material, MeshData
+    from rustray_amd.scene import Scene, get_transformation, inverse_affine
+    rng = np.random.default_rng(seed)
+    fs = FlatScene()
+    fs.name = f"many{n_spheres + n_quads}"
+    eye4 = np.eye(4, dtype=np.float32)
+    mats = []
+    for k in range(6):
+        m = Material(base_color=tuple(rng.uniform(0.2, 1.0, 3)), specular_color=(0.3, 0.3, 0.3), shininess=40.0)
+        if k == 1:
+            m.reflectivity = 0.5
+        if k == 2:
+            m.alpha, m.refraction_index = 0.5, 1.3
+        fs.materials.append(m); fs.materials.append(Scene._cache_of(m))
+        mats.append((len(fs.materials) - 2, len(fs.materials) - 1))
+    p = np.asarray([[-60, -1, 10], [60, -1, 10], [60, -1, -120], [-60, -1, -120]], np.float32)
+    fs.meshes.append(MeshData(positions=p, indices=np.asarray([[0, 1, 2], [0, 2, 3]], np.uint32)))
+    q = np.asarray([[-0.3, 0, -0.3], [0.3, 0, -0.3], [0.3, 0.6, 0.3], [-0.3, 0.6, 0.3]], np.float32)
+    fs.meshes.append(MeshData(positions=q, indices=np.asarray([[0, 1, 2], [0, 2, 3]], np.uint32)))
+    fs.items.append(Item(kind=1, id=1, material=mats[0][0], material_cache=mats[0][1], mesh=0, trans=eye4.copy(), trans_inv=eye4.copy(),
+                         bbox_min=tuple(p.min(0)), bbox_max=tuple(p.max(0)), name="floor"))
+    n = n_spheres + n_quads
+    side = int(np.ceil(np.sqrt(n)))
+    for i in range(n):
+        gx, gz = i % side, i // side
+        pos = (-40.0 + 80.0 * (gx + 0.5) / side + float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.6, 0.4)), -8.0 - 100.0 * (gz + 0.5) / side)
+        mi, ci = mats[int(rng.integers(0, 6))]
+        if i < n_spheres:
+            r = float(rng.uniform(0.15, 0.35))
+            t = get_transformation(eye4, pos, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0))
+            fs.items.append(Item(kind=0, id=2 + i, material=mi, material_cache=ci, radius=r, trans=t, trans_inv=inverse_affine(t), bbox_min=(-r, -r, -r), bbox_max=(r, r, r)))
+        else:
+            t = get_transformation(eye4, pos, (1.0, 1.0, 1.0), (0.0, float(rng.uniform(0, 6.28)), 0.0))
+            fs.items.append(Item(kind=1, id=2 + i, material=mi, material_cache=ci, mesh=1, trans=t, trans_inv=inverse_affine(t), bbox_min=tuple(q.min(0)), bbox_max=tuple(q.max(0))))
+    fs.lights = [Light(pos=(5.0, 30.0, -20.0), intensity=900.0)]
+    fs.meta = {"camera": dict(width=64, height=48, fov=float(np.float32(np.radians(55.0))), eye_pos=[0.0, 6.0, 6.0], up=[0.0, 1.0, 0.0], dir=[0.0, -0.25, -1.0],
+                              clipping_near=0.1, clipping_far=300.0)}
+    return fs
+
+
+def test_more_items_than_the_top_level_used_to_hold(hip, oracle):
+    """The reference's `items` is a Vec (src/scene.rs:69-83).  Up to round 3 item 4 097 made rr_scene_create fail (one item per leaf
+    under a 12-level top tree); now the top level takes ceil(log2 n) levels out of the per-mesh trees' share of the traversal stack.
+    5 000 items (13 levels) against the oracle, which walks its own item tree."""
+    fs = _many_items_scene(3000, 1999)
+    assert len(fs.items) == 5000
+    _check(hip, oracle, fs, 96, 64, make_config(samples=2, monte_carlo=True, seed=4, max_recursion=3))
+
+
+def test_item_count_beyond_rr_max_items_is_refused_with_a_message(hip):
+    """RR_MAX_ITEMS = 2^20 (include/rustray_hip.h): one more is RR_ERR_UNSUPPORTED, not a crash and not a truncated scene."""
+    import ctypes as C
+    from rustray_amd.flat import rr_flat_scene, rr_item, rr_material
+    n = (1 << 20) + 1
+    items = (rr_item * n)()
+    mats = (rr_material * 1)()
+    for k in range(8):
+        mats[0].texture[k] = -1
+    eye = [1.0 if i % 5 == 0 else 0.0 for i in range(16)]
+    proto = rr_item()
+    proto.kind, proto.mesh, proto.radius, proto.visible = 0, -1, 1.0, 1
+    for i in range(16):
+        proto.trans[i] = proto.trans_inv[i] = eye[i]
+    for i in range(3):
+        proto.bbox_min[i], proto.bbox_max[i] = -1.0, 1.0
+    C.memmove(items, bytes(proto) * n, C.sizeof(rr_item) * n)
+    cs = rr_flat_scene()
+    cs.abi_version, cs.n_items, cs.n_materials = 2, n, 1
+    cs.items, cs.materials = C.cast(items, C.POINTER(rr_item)), C.cast(mats, C.POINTER(rr_material))
+    h = C.c_void_p(None)
+    rc = hip.lib().rr_scene_create(C.byref(cs), 0, C.byref(h))
+    assert rc == -2 and not h and "RR_MAX_ITEMS" in hip.lib().rr_last_error().decode()

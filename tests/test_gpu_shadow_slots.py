@@ -71,3 +71,36 @@ def test_any_number_of_lights(hip, oracle):
         res = compare_frames(a, ref)
         assert res["n_rgb_over"] == 0 and res["n_id_diff"] == 0 and res["nan_mismatch"] == 0, (n_on, res)
         assert 0 < st["shadow_rays"] <= ref["counters"]["rays_shadow"] and st["shaded_hits"] == ref["counters"]["shaded_hits"], n_on
+
+
+def test_hundreds_of_unshadowed_lights_do_not_overflow_the_lane_sums(hip, oracle):
+    """the 32-bit fixed-point lane sums of k_shade are flushed every 32 enabled lights; the flush sat inside the branch of
+    a light with a non-zero term, so a back-facing light number 31 or 63 skipped it.  140 enabled lights on materials that do NOT
+    receive shadows (every term is added in k_shade itself), bright enough that 96 unflushed terms would pass 2^31 (each term ~ 1.5
+    at scale 2^24), every light whose ordinal is 31 mod 32 placed BELOW the floor so that its term is exactly zero."""
+    import copy
+    fs = _scene(9119)
+    for m in fs.materials:
+        m.receive_shadow = False
+    rng = np.random.default_rng(41)
+    proto = fs.lights[0]
+    lights = []
+    for i in range(140):
+        l = copy.copy(proto)
+        l.enabled = True
+        l.light_type = 0   # directional: intensity is the term's scale, whatever the distance
+        l.color = (1.0, 1.0, 1.0)
+        l.intensity = 1.5
+        down = (i % 32) == 31
+        l.dir = (float(rng.uniform(-0.2, 0.2)), 1.0 if down else -1.0, float(rng.uniform(-0.2, 0.2)))   # `down`: shines upwards, from below every surface that faces up
+        lights.append(l)
+    fs.lights = lights
+    cam = camera_for(fs, 48, 32).c_struct()
+    cfg = make_config(samples=2, monte_carlo=False, seed=1, max_recursion=1)
+    with hip.DeviceScene(fs, 0) as ds:
+        a = ds.render(cam, cfg)
+        assert ds.stats()["shadow_rays"] == 0
+    ref = oracle.render(fs.c_struct(), cam, cfg, n_threads=8)
+    res = compare_frames(a, ref)
+    assert res["n_rgb_over"] == 0 and res["n_id_diff"] == 0 and res["nan_mismatch"] == 0, res
+    assert (a["rgba"][..., :3] == 255).mean() > 0.1   # the sums really are large: most lit pixels saturate
