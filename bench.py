@@ -17,8 +17,12 @@ Raytracing::trace call of the reference (primary, reflection, refraction, shadow
 The timed frame is the CONTRACT frame: RGBA8 plus the aux buffers PixelData carries
 (normal, depth, object id: reference src/raytracing.rs:57-70), resident in HBM at the end.
 Extra keys (rank 0, N = 1): `rgba_only_ms` (aux buffers not requested), `rr_render_host_ms`
-(the same frame through rr_render into host memory, PCIe included), and `other_configs`
-(helmet_syn 1280x720x64, lotus_syn 1280x720x512 + DOF: stand-ins for BASELINE configs C3 / C5).
+(the same frame through rr_render into host memory, PCIe included), `update_transforms_ms` / `pick_ms` (the animation step and
+the pick query on the resident scene), and `other_configs`: every other BASELINE config at its own size and sample count
+(C1 spheres 256x256x1 mc=0, C2 monkey 800x600x16, and the stand-ins helmet_syn 1280x720x64, lotus_syn 1280x720x512 + DOF for
+C3 / C5), each with its device time, launches and -- where profiles/ holds SQ counters of the same build for it -- its own `roofline`.
+`roofline.kernels` prices EVERY kernel build of the frame (k_trace_closest / k_shade / k_trace_shadow, level 1 `<true>` and the deeper
+levels `<false>`) from its live launch times.
 
 N > 1 additionally reports what shows that RCCL really saw N ranks (`dist_backend`, `world_size` as torch.distributed
 reports it, every rank's device), `frame_checksum_matches_single_gpu` (rank 0 renders the whole frame alone after the
@@ -97,6 +101,7 @@ def build_workload(scene, width, height, spp, monte_carlo=1, scene_root=None):
             fs = synthetic.helmet_syn()
         else:
             fs = load_scene(scene)
+            fs.name = scene   # (the fixture files carry the reference scene files' own titles)
         fs.meta = dict(fs.meta)
         fs.meta["data"] = "synthetic" if fs.meta.get("synthetic") else "fixture"
     st = dict(fs.meta["camera"])
@@ -166,6 +171,69 @@ def cpu_baseline(fs, cam, args):
                 ms_per_frame_scaled=dt * 1000.0 * args.spp / args.cpu_spp, bvh_build_s=t_build), ab
 
 
+KERNEL_BUILDS = (  # kernel build -> (its ms / launches fields in rr_frame_stats)
+    ("k_trace_closest<true>", "ms_trace_closest_level1", "launches_trace_closest_level1"),
+    ("k_shade<true>", "ms_shade_level1", "launches_shade_level1"),
+    ("k_trace_shadow<true>", "ms_trace_shadow_level1", "launches_trace_shadow_level1"),
+    ("k_trace_closest<false>", None, None), ("k_shade<false>", None, None), ("k_trace_shadow<false>", None, None))
+
+
+def kernel_rooflines(scene_name, width, height, spp, acc, frames, source_id):
+    """`roofline` of one workload from the LIVE per-launch HIP-event times in `acc` (rr_frame_stats summed over `frames` frames) and the
+    committed SQ counters of the same build and workload (profiles/rNN_sq_counters[_<scene>].json, tools/profile_round.sh): for every
+    kernel build, achieved = VALU wave-instructions per frame (a property of code + scene) / live kernel time per frame, against the
+    VALU issue peak.  The headline entry is the level-1 closest-hit build; `kernels` has all of them.  None when nothing was timed."""
+    if acc.get("launches_trace_closest_level1", 0) <= 0:
+        return None
+    launches = acc["launches_trace_closest_level1"]
+    roof = {"bound": "valu_issue", "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "kernel": "k_trace_closest<true>", "launches": launches,
+            "avg_launch_ms": acc["ms_trace_closest_level1"] / launches, "rays_per_launch": acc["primary_rays"] / launches,
+            "achieved": None, "frac": None, "traffic": None}
+    sfx = "" if scene_name == "sponza_syn" else "_" + scene_name
+    sq, sq_path = newest_profile(f"r[0-9][0-9]_sq_counters{sfx}.json")   # the round's final profile (rNNa / rNNb are experiments)
+    same_workload = bool(sq) and sq.get("workload", "").startswith(f"{scene_name} {width}x{height} {spp}spp")
+    same_build = bool(sq) and sq.get("source_id") == source_id
+    if sq and not (same_workload and same_build):
+        # the instruction count is a property of code + scene: a count taken from another build or workload is not mixed with this run's time
+        roof["frac_reason"] = (f"{sq_path} was collected on source_id {sq.get('source_id')} / workload {sq.get('workload', '')[:40]!r}; "
+                               f"this run is source_id {source_id}: re-run tools/profile_round.sh")
+    elif not sq:
+        roof["frac_reason"] = f"no profiles/rNN_sq_counters{sfx}.json for this workload"
+    ms_frame = {"k_trace_closest<true>": acc["ms_trace_closest_level1"], "k_shade<true>": acc.get("ms_shade_level1", 0.0), "k_trace_shadow<true>": acc.get("ms_trace_shadow_level1", 0.0),
+                "k_trace_closest<false>": acc["ms_trace_closest"] - acc["ms_trace_closest_level1"], "k_shade<false>": acc["ms_shade"] - acc.get("ms_shade_level1", 0.0),
+                "k_trace_shadow<false>": acc["ms_trace_shadow"] - acc.get("ms_trace_shadow_level1", 0.0)}
+    n_launch = {"k_trace_closest<true>": launches, "k_shade<true>": acc.get("launches_shade_level1", 0), "k_trace_shadow<true>": acc.get("launches_trace_shadow_level1", 0),
+                "k_trace_closest<false>": acc["launches_trace_closest"] - launches, "k_shade<false>": acc["launches_shade"] - acc.get("launches_shade_level1", 0),
+                "k_trace_shadow<false>": acc["launches_trace_shadow"] - acc.get("launches_trace_shadow_level1", 0)}
+    kernels = {}
+    for name, _, _ in KERNEL_BUILDS:
+        if n_launch[name] <= 0:
+            continue
+        ms = ms_frame[name] / frames
+        k = {"launches_per_frame": n_launch[name] / frames, "ms_per_frame": ms, "avg_launch_ms": ms_frame[name] / n_launch[name], "frac": None}
+        c = (sq or {}).get("kernels", {}).get(name) if (same_workload and same_build) else None
+        if c and c.get("SQ_INSTS_VALU") and ms > 0:
+            k["valu_wave_insts_per_frame"] = c["SQ_INSTS_VALU"]
+            k["achieved"] = c["SQ_INSTS_VALU"] / (ms * 1e-3) / 1e9
+            k["frac"] = k["achieved"] / VALU_PEAK_GINST
+            k["wait_any_frac"] = c.get("wait_any_frac")            # share of wave cycles parked in s_waitcnt
+            k["wait_inst_any_frac"] = c.get("wait_inst_any_frac")  # share stalled at issue
+            k["avg_active_lanes_per_valu"] = c.get("avg_active_lanes_per_valu")
+        kernels[name] = k
+    k1 = kernels.get("k_trace_closest<true>", {})
+    if k1.get("frac") is not None:
+        roof["achieved"], roof["frac"] = k1["achieved"], k1["frac"]
+        roof["valu_wave_insts_per_ray"] = k1["valu_wave_insts_per_frame"] / (acc["primary_rays"] / frames)
+        roof["sq_counters"] = sq_path
+        roof["sq_wait_any_frac_of_wave_cycles"] = k1.get("wait_any_frac")
+        roof["sq_wait_inst_any_frac_of_wave_cycles"] = k1.get("wait_inst_any_frac")
+    roof["kernels"] = kernels
+    all_l = acc["launches_trace_closest"]
+    roof["all_levels"] = {"launches": all_l, "avg_launch_ms": acc["ms_trace_closest"] / max(all_l, 1),
+                          "rays_per_launch": (acc["primary_rays"] + acc["secondary_rays"]) / max(all_l, 1)}
+    return roof
+
+
 def extras(args, ds, camc, cfg, step, fence):
     """Rank 0, N = 1: the same frame without aux buffers, the same frame through rr_render into host memory, and one
     frame each of the stand-ins for BASELINE configs C3 / C5."""
@@ -183,17 +251,38 @@ def extras(args, ds, camc, cfg, step, fence):
     out["rgba_only_ms"] = timed(lambda: step(aux=False))
     out["rr_render_host_ms"] = timed(lambda: ds.render(camc, cfg, aux=True))   # RGBA8 + aux over PCIe into pageable host arrays
     out["rr_render_host_rgba_only_ms"] = timed(lambda: ds.render(camc, cfg, aux=False))
+    # the frame's side doors, on the resident bench scene: an animation step that moves nothing (every item's own matrices back in:
+    # rr_scene_update_transforms re-derives world normals, surface boxes and the top level whatever the matrices are), and one pick
+    import statistics
+    from rustray_amd import capi as _capi
+    t = np.stack([np.asarray(it.trans, np.float32) for it in ds._flat.items])
+    ti = np.stack([np.asarray(it.trans_inv, np.float32) for it in ds._flat.items])
+    ts = []
+    for _ in range(6):
+        fence(); t0 = time.perf_counter(); ds.update_transforms(t, ti); ts.append((time.perf_counter() - t0) * 1000.0)
+    out["update_transforms_ms"] = statistics.median(ts[1:])   # host wall time of the whole call, median of 5 (the first call allocates)
+    ts = []
+    for k in range(6):
+        t0 = time.perf_counter(); ds.pick(camc, args.width // 2 + k, args.height // 2); ts.append((time.perf_counter() - t0) * 1000.0)
+    out["pick_ms"] = statistics.median(ts[1:])
+    # every other BASELINE config at its own size and sample count, one frame each (C1 spheres, C2 monkey, C3 / C5 stand-ins)
     other = {}
-    for scene, spp in (("helmet_syn", 64), ("lotus_syn", 512)):
-        fs2, cam2, cfg2 = build_workload(scene, args.width, args.height, spp, 1)
-        with capi.DeviceScene(fs2, ds.device) as d2:
+    for scene, w, h, spp, mc in (("spheres", 256, 256, 1, 0), ("monkey", 800, 600, 16, 1), ("helmet_syn", args.width, args.height, 64, 1), ("lotus_syn", args.width, args.height, 512, 1)):
+        fs2, cam2, cfg2 = build_workload(scene, w, h, spp, mc)
+        with _capi.DeviceScene(fs2, ds.device) as d2:
+            d2.set_profiling(True)
             c2 = cam2.c_struct()
             ms = timed(lambda: d2.render(c2, cfg2, aux=True), reps=1)
             st = d2.stats()
         rays = st["primary_rays"] + st["secondary_rays"] + st["shadow_rays"]
-        other[f"{scene} {args.width}x{args.height} {spp}spp" + (" +DOF" if cfg2.aperture_size > 1.0 else "")] = {
-            "ms_per_frame_host": ms, "ms_per_frame_device": st["ms_total"], "mrays_per_s": rays / (st["ms_total"] * 1e-3) / 1e6,
-            "rays": rays, "items": len(fs2.items), "triangles": fs2.n_triangles_instanced()}
+        entry = {"ms_per_frame_host": ms, "ms_per_frame_device": st["ms_total"], "mrays_per_s": rays / (st["ms_total"] * 1e-3) / 1e6,
+                 "rays": rays, "items": len(fs2.items), "triangles": fs2.n_triangles_instanced(),
+                 "launches": st["launches_trace_closest"] + st["launches_shade"] + st["launches_trace_shadow"],
+                 "kernel_ms_per_frame": {"k_trace_closest": st["ms_trace_closest"], "k_shade": st["ms_shade"], "k_trace_shadow": st["ms_trace_shadow"]}}
+        r2 = kernel_rooflines(scene, w, h, spp, st, 1, _capi.source_id())
+        if r2 is not None:
+            entry["roofline"] = r2
+        other[f"{scene} {w}x{h} {spp}spp monte_carlo={mc}" + (" +DOF" if cfg2.aperture_size > 1.0 else "")] = entry
     out["other_configs"] = other
     return out
 
@@ -260,6 +349,28 @@ def start_one_process_helper(args, world):
         return subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     except OSError as e:
         return e
+
+
+def wait_for_ranks_to_leave(pids, limit_s=20.0):
+    """Rank 0, after destroy_process_group: waits until the other ranks' processes are gone (they exit right after the barrier; a rank
+    still alive holds its GPU context and would share the device with the one-process leg).  Bounded; says what happened."""
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        except PermissionError:
+            return True
+        try:   # a zombie (exited, not yet reaped by the launcher) has left its GPU
+            return open(f"/proc/{pid}/stat").read().rsplit(")", 1)[1].split()[0] != "Z"
+        except OSError:
+            return False
+    t0 = time.perf_counter()
+    left = [p for p in pids if alive(p)]
+    while left and time.perf_counter() - t0 < limit_s:
+        time.sleep(0.05)
+        left = [p for p in left if alive(p)]
+    return {"waited_s": time.perf_counter() - t0, "ranks_gone": not left, "still_alive": left}
 
 
 def finish_one_process_helper(helper, timeout=300):
@@ -356,7 +467,8 @@ def main():
     fence()
     acc = dict(primary_rays=0, secondary_rays=0, shadow_rays=0, shaded_hits=0, ms_trace_closest=0.0, ms_trace_shadow=0.0,
                ms_shade=0.0, launches_trace_closest=0, launches_trace_shadow=0, launches_shade=0, ms_total=0.0, ms_binning=0.0, binned_rays=0,
-               ms_trace_closest_level1=0.0, launches_trace_closest_level1=0)
+               ms_trace_closest_level1=0.0, launches_trace_closest_level1=0, ms_shade_level1=0.0, launches_shade_level1=0,
+               ms_trace_shadow_level1=0.0, launches_trace_shadow_level1=0)
     t0 = time.perf_counter()
     frame = None
     for it in range(args.steps):
@@ -441,43 +553,21 @@ def main():
             small = argparse.Namespace(**vars(args)); small.cpu_spp = 1
             _, ab = cpu_baseline(fs, _Cam.from_state(st), small)
         # roofline of the dominant kernel (rank 0's launches), see the module docstring: the level-1 build of the closest-hit
-        # kernel, `k_trace_closest<true>` in the rocprofv3 kernel stats (one launch per batch, the frame is one batch)
-        if acc["launches_trace_closest_level1"] > 0:
-            launches = acc["launches_trace_closest_level1"]
-            avg_ms = acc["ms_trace_closest_level1"] / launches
-            rays_per_launch = acc["primary_rays"] / launches
-            sq, sq_path = newest_profile("r[0-9][0-9]_sq_counters.json")   # the round's final profile (rNNa / rNNb are experiments)
+        # kernel, `k_trace_closest<true>` in the rocprofv3 kernel stats (one launch per batch, the frame is one batch) -- and, beside
+        # it under `kernels`, every kernel build of the frame with its own live launch time
+        roof = kernel_rooflines(fs.name, args.width, args.height, args.spp, acc, args.steps, capi.source_id())
+        if roof is not None:
             hbm, hbm_path = newest_profile("r[0-9][0-9]_hbm_traffic.json")
-            roof = {"bound": "valu_issue", "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "kernel": "k_trace_closest<true>", "launches": launches,
-                    "avg_launch_ms": avg_ms, "rays_per_launch": rays_per_launch, "achieved": None, "frac": None, "traffic": None}
-            k1 = (sq or {}).get("kernels", {}).get("k_trace_closest<true>")
-            same_workload = bool(k1) and sq.get("workload", "").startswith(f"{fs.name} {args.width}x{args.height} {args.spp}spp")
-            same_build = bool(sq) and sq.get("source_id") == capi.source_id()
-            if k1 and not (same_workload and same_build):
-                # the instruction count is a property of code + scene: a count taken from another build or workload is not mixed with this run's time
-                roof["frac_reason"] = (f"{sq_path} was collected on source_id {sq.get('source_id')} / workload {sq.get('workload', '')[:40]!r}; "
-                                       f"this run is source_id {capi.source_id()}: re-run tools/profile_round.sh")
-            if k1 and same_workload and same_build:
-                vpr = k1["valu_insts_per_ray"]
-                roof["achieved"] = vpr * rays_per_launch / (avg_ms * 1e-3) / 1e9
-                roof["frac"] = roof["achieved"] / VALU_PEAK_GINST
-                roof["valu_wave_insts_per_ray"] = vpr
-                roof["sq_counters"] = sq_path
-                roof["sq_wait_any_frac_of_wave_cycles"] = k1.get("wait_any_frac")
-                roof["sq_wait_inst_any_frac_of_wave_cycles"] = k1.get("wait_inst_any_frac")
             h1 = (hbm or {}).get("kernels", {}).get("k_trace_closest<true>")
-            if h1:
+            if h1 and roof.get("avg_launch_ms"):
                 roof["traffic"] = h1["hbm_bytes_per_launch_corrected"]
                 roof["traffic_source"] = hbm_path
-                roof["hbm_measured_frac"] = roof["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-            if ab is not None:
+                roof["hbm_measured_frac"] = roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if ab is not None and roof.get("avg_launch_ms"):
                 bpr = ab["bytes_per_closest_ray"]
                 roof["algorithmic_bytes_per_ray"] = bpr
-                roof["algorithmic_gbs"] = bpr * rays_per_launch / (avg_ms * 1e-3) / 1e9   # cache-served: may exceed HBM peak
+                roof["algorithmic_gbs"] = bpr * roof["rays_per_launch"] / (roof["avg_launch_ms"] * 1e-3) / 1e9   # cache-served: may exceed HBM peak
                 roof["whole_frame_bytes_per_ray"] = ab["bytes_per_ray"]
-            all_l = acc["launches_trace_closest"]
-            roof["all_levels"] = {"launches": all_l, "avg_launch_ms": acc["ms_trace_closest"] / max(all_l, 1),
-                                  "rays_per_launch": (acc["primary_rays"] + acc["secondary_rays"]) / max(all_l, 1)}
             result["roofline"] = roof
         result["kernel_ms_per_frame"] = {"k_trace_closest": acc["ms_trace_closest"] / args.steps,
                                          "k_trace_shadow": acc["ms_trace_shadow"] / args.steps,
@@ -499,7 +589,7 @@ def main():
         if helper is not None:
             # the one-process leg runs now: the collective is torn down, this rank's handle is closed and the other ranks are
             # exiting, so rr_render_multi has the N devices to itself (a rank waiting in an RCCL barrier would spin on its GPU)
-            time.sleep(2.0)
+            result["one_process_wait"] = wait_for_ranks_to_leave([r["pid"] for r in (dist_info or {}).get("ranks", []) if r["pid"] != os.getpid()])
             result["one_process"] = finish_one_process_helper(helper)
         print(json.dumps(result))
 

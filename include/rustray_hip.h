@@ -35,8 +35,9 @@ extern "C" {
 /* Version of this header's struct layouts and entry points.  rr_scene_create refuses a flat scene that names another
  * version, and rr_abi_version() reports what the loaded library was built with, so a caller compiled against an older
  * header (round 1: a shorter rr_frame_stats, rr_scene_set_profiling) fails at the first call instead of being written
- * past its structs.  2: rr_frame_stats grew (level-1 timing, binning, multi-GPU exchange), rr_tuning, rr_abi_version. */
-#define RR_ABI_VERSION 2u
+ * past its structs.  2: rr_frame_stats grew (level-1 timing, binning, multi-GPU exchange), rr_tuning, rr_abi_version.
+ * 3: rr_frame_stats carries the level-1 share of the shade and shadow kernels too (one roofline per kernel build in bench.py). */
+#define RR_ABI_VERSION 3u
 
 typedef enum rr_status {
     RR_OK = 0,
@@ -273,6 +274,11 @@ typedef struct rr_frame_stats {
     uint32_t multi_staged_links;  /* handles whose buffers were staged through pinned host memory (no peer access between the devices) */
     uint32_t _pad;
     double ms_multi_exchange;     /* host wall time from the last device finishing its tiles to the frame being in `out` */
+    /* the level-1 share of ms_shade / ms_trace_shadow (the k_shade<true> / k_trace_shadow<true> builds), as ms_trace_closest_level1 (ABI 3) */
+    double ms_shade_level1;
+    uint64_t launches_shade_level1;
+    double ms_trace_shadow_level1;
+    uint64_t launches_trace_shadow_level1;
 } rr_frame_stats;
 
 /* Execution knobs of the device path.  None of them changes a single output bit (fixed-point accumulation makes

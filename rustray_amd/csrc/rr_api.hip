@@ -144,7 +144,7 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
-struct TimedLaunch { hipEvent_t a, b; int kind; };
+struct TimedLaunch { hipEvent_t a, b; int kind; }; // kind: 0 closest-hit (deeper levels), 4 (level 1); 1 shadow, 6 (level 1); 2 shade, 5 (level 1); 3 binning
 struct ItemHost { uint32_t kind; int32_t material, material_cache; bool visible, flip_normals, mesh_has_normals, mesh_degenerate; int32_t mesh; };
 
 struct rr_scene {
@@ -1083,8 +1083,10 @@ static void resolve_timers(rr_scene* s) {
         if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
             if (t.kind == 0 || t.kind == 4) { s->stats.ms_trace_closest += ms; s->stats.launches_trace_closest++; }
             if (t.kind == 4) { s->stats.ms_trace_closest_level1 += ms; s->stats.launches_trace_closest_level1++; }
-            if (t.kind == 1) { s->stats.ms_trace_shadow += ms; s->stats.launches_trace_shadow++; }
-            else if (t.kind == 2) { s->stats.ms_shade += ms; s->stats.launches_shade++; }
+            if (t.kind == 1 || t.kind == 6) { s->stats.ms_trace_shadow += ms; s->stats.launches_trace_shadow++; }
+            if (t.kind == 6) { s->stats.ms_trace_shadow_level1 += ms; s->stats.launches_trace_shadow_level1++; }
+            if (t.kind == 2 || t.kind == 5) { s->stats.ms_shade += ms; s->stats.launches_shade++; }
+            if (t.kind == 5) { s->stats.ms_shade_level1 += ms; s->stats.launches_shade_level1++; }
             else if (t.kind == 3) { s->stats.ms_binning += ms; }
         }
         s->event_pool.push_back(t.a); s->event_pool.push_back(t.b);
@@ -1368,7 +1370,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
                 uint32_t* shead = words(1);
                 if (!sq_counts || !shead) return fail(RR_ERR_UNSUPPORTED, "out of memory for the per-launch counters of a batch");
                 {
-                    ScopedTimer t(s, st, 2);
+                    ScopedTimer t(s, st, d == 1 ? 5 : 2);
                     if (d == 1) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(RR_BLOCK), 0, st, s->shade_const.as<DShadeConst>(), s->region_xy.as<uint32_t>(), pr, qin, count,
                                                    (uint32_t)c0, (uint32_t)c1, qout, child_count, SQ, sq_counts, segcap, sq_valid, sq_chunk_cap, acc, counters);
                     else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(RR_BLOCK), 0, st, s->shade_const.as<DShadeConst>(), s->region_xy.as<uint32_t>(), pr, qin, count,
@@ -1382,7 +1384,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
                     HIP_TRY(hipEventRecord(s->count_ready, st));
                 }
                 if (L) {
-                    ScopedTimer t(s, st, 1);
+                    ScopedTimer t(s, st, d == 1 ? 6 : 1);
                     if (sq_fixed) {
                         const uint32_t sq_packets = (sq_chunk_cap / RR_WAVE) * L;
                         const int sgrid = (int)std::min<uint64_t>(((uint64_t)sq_packets * RR_WAVE + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)shadow_grid);

@@ -18,7 +18,7 @@ from typing import List, Optional
 
 import numpy as np
 
-RR_ABI_VERSION = 2
+RR_ABI_VERSION = 3
 RR_TEX_COUNT = 8
 TEX_NAMES = ["base", "ambient", "specular", "normal", "alpha", "roughness",
              "ambient_occlusion", "reflectivity"]  # TextureType order, src/shape/mod.rs:633-643
@@ -117,6 +117,8 @@ class rr_frame_stats(C.Structure):
         ("ms_trace_closest_level1", C.c_double), ("launches_trace_closest_level1", C.c_uint64),
         ("multi_devices", C.c_uint32), ("multi_peer_links", C.c_uint32), ("multi_staged_links", C.c_uint32), ("_pad", C.c_uint32),
         ("ms_multi_exchange", C.c_double),
+        ("ms_shade_level1", C.c_double), ("launches_shade_level1", C.c_uint64),
+        ("ms_trace_shadow_level1", C.c_double), ("launches_trace_shadow_level1", C.c_uint64),
     ]
 
 

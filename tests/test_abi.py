@@ -36,9 +36,9 @@ def test_abi_version_is_reported_and_checked():
     header_version = int(re.search(r"#define RR_ABI_VERSION (\d+)u", src).group(1))
     L = capi.lib()
     L.rr_abi_version.restype = C.c_uint32
-    assert header_version == flat.RR_ABI_VERSION == L.rr_abi_version() == 2
-    # rr_frame_stats as the header lists it: 17 8-byte fields of round 2 + 4 u32 + 1 double of the multi-GPU exchange
-    assert C.sizeof(flat.rr_frame_stats) == 17 * 8 + 4 * 4 + 8
+    assert header_version == flat.RR_ABI_VERSION == L.rr_abi_version() == 3
+    # rr_frame_stats as the header lists it: 17 8-byte fields of round 2 + 4 u32 + 1 double of the multi-GPU exchange + 4 8-byte level-1 fields (ABI 3)
+    assert C.sizeof(flat.rr_frame_stats) == 17 * 8 + 4 * 4 + 8 + 4 * 8
 
 
 def test_render_multi_locks_handles_in_address_order():

@@ -190,7 +190,7 @@ def test_item_count_beyond_rr_max_items_is_refused_with_a_message(hip):
         proto.bbox_min[i], proto.bbox_max[i] = -1.0, 1.0
     C.memmove(items, bytes(proto) * n, C.sizeof(rr_item) * n)
     cs = rr_flat_scene()
-    cs.abi_version, cs.n_items, cs.n_materials = 2, n, 1
+    cs.abi_version, cs.n_items, cs.n_materials = 3, n, 1
     cs.items, cs.materials = C.cast(items, C.POINTER(rr_item)), C.cast(mats, C.POINTER(rr_material))
     h = C.c_void_p(None)
     rc = hip.lib().rr_scene_create(C.byref(cs), 0, C.byref(h))
