@@ -22,6 +22,7 @@
 #include <exception>
 #include <new>
 #include <stdexcept>
+#include <limits>
 #include <map>
 #include <memory>
 #include <functional>
@@ -160,7 +161,8 @@ struct rr_scene {
     // per item: the extent of its surface along the rows of its transform (k_item_spans: minima, maxima, largest |local coordinate|; 9 doubles),
     // read back after every upload of the items' transforms; the top level's surface boxes are derived from it (exact_world_box)
     std::vector<double> h_spans;
-    DevBuf spans;
+    DevBuf spans, item_chunks;              // item_chunks: (item, first triangle) per workgroup of k_world_normals / k_item_spans (RR_ITEM_CHUNK triangles each)
+    std::vector<uint32_t> h_chunk_item;     // the item of every chunk (chunks of one item are consecutive)
     std::vector<uint32_t> tex_width;
     std::vector<DTexture> h_textures; // descriptors of the uploaded images (copied into the material records, make_dmaterial)
     uint32_t n_materials = 0;
@@ -657,12 +659,34 @@ static int derive_from_transforms(rr_scene* s) {
     const uint32_t n = (uint32_t)s->h_items.size();
     s->h_spans.clear();
     if (n == 0) return RR_OK;
-    HIP_TRY(s->spans.reserve(9 * sizeof(double) * (size_t)n));
-    hipLaunchKernelGGL(k_world_normals, dim3(n), dim3(RR_BLOCK), 0, nullptr, s->items.as<DItem>(), n, s->tris.as<DTri>(), s->flat_normals.as<float4>());
-    hipLaunchKernelGGL(k_item_spans, dim3(n), dim3(RR_BLOCK), 0, nullptr, s->items.as<DItem>(), n, s->tris.as<DTri>(), s->spans.as<double>());
+    if (s->h_chunk_item.empty()) { // the chunk map depends on the items' triangle counts only: laid out once
+        std::vector<uint2> chunks;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t nt = (s->h_items[i].flags & RR_IF_SPHERE) ? 0u : s->h_items[i].n_tris;
+            for (uint32_t first = 0; first == 0u || first < nt; first += RR_ITEM_CHUNK) { chunks.push_back(make_uint2(i, first)); s->h_chunk_item.push_back(i); }
+        }
+        HIP_TRY(s->item_chunks.reserve(chunks.size() * sizeof(uint2)));
+        HIP_TRY(hipMemcpy(s->item_chunks.p, chunks.data(), chunks.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        HIP_TRY(s->spans.reserve(9 * sizeof(double) * chunks.size()));
+    }
+    const size_t nc = s->h_chunk_item.size();
+    if (nc > 0x7fffffffull) return fail(RR_ERR_UNSUPPORTED, "%zu chunks of instanced triangles", nc);
+    hipLaunchKernelGGL(k_world_normals, dim3((uint32_t)nc), dim3(RR_BLOCK), 0, nullptr, s->items.as<DItem>(), s->item_chunks.as<uint2>(), s->tris.as<DTri>(), s->flat_normals.as<float4>());
+    hipLaunchKernelGGL(k_item_spans, dim3((uint32_t)nc), dim3(RR_BLOCK), 0, nullptr, s->items.as<DItem>(), s->item_chunks.as<uint2>(), s->tris.as<DTri>(), s->spans.as<double>());
     HIP_TRY(hipGetLastError());
+    std::vector<double> part(9 * nc);
+    HIP_TRY(hipMemcpy(part.data(), s->spans.p, 9 * sizeof(double) * nc, hipMemcpyDeviceToHost)); // (waits for both kernels)
     s->h_spans.resize(9 * (size_t)n);
-    HIP_TRY(hipMemcpy(s->h_spans.data(), s->spans.p, 9 * sizeof(double) * (size_t)n, hipMemcpyDeviceToHost)); // (waits for both kernels)
+    for (uint32_t i = 0; i < n; i++)
+        for (int k = 0; k < 9; k++) s->h_spans[9 * (size_t)i + k] = k < 3 ? std::numeric_limits<double>::infinity() : (k < 6 ? -std::numeric_limits<double>::infinity() : 0.0);
+    for (size_t c = 0; c < nc; c++) {
+        double* d = &s->h_spans[9 * (size_t)s->h_chunk_item[c]];
+        const double* q = &part[9 * c];
+        for (int k = 0; k < 9; k++) {
+            if (q[k] != q[k]) d[k] = q[k];                       // a NaN chunk poisons the item (the corner box is kept for it)
+            else if (d[k] == d[k]) d[k] = k < 3 ? std::min(d[k], q[k]) : std::max(d[k], q[k]);
+        }
+    }
     return RR_OK;
 }
 

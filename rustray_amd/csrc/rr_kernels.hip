@@ -2057,11 +2057,15 @@ __global__ __launch_bounds__(RR_BLOCK, RR_SHADE_WAVES) void k_shade(const DShade
 
 // The flat world normals of every mesh item (DSceneView::flat_normals): one workgroup per item, both signs of every triangle's
 // normal through the item's transform.  Run at scene creation and after rr_scene_update_transforms.
-__global__ __launch_bounds__(RR_BLOCK) void k_world_normals(const DItem* __restrict__ items, uint32_t n_items, const DTri* __restrict__ tris, float4* __restrict__ out) {
-    if (blockIdx.x >= n_items) return;
-    const DItem& it = items[blockIdx.x];
+// One workgroup per CHUNK of an item's triangles (`chunks`: (item, first triangle) per workgroup, RR_ITEM_CHUNK triangles each, laid out by
+// rr_scene_create: a mesh of a million triangles is 123 workgroups, not one).
+#define RR_ITEM_CHUNK 8192u
+__global__ __launch_bounds__(RR_BLOCK) void k_world_normals(const DItem* __restrict__ items, const uint2* __restrict__ chunks, const DTri* __restrict__ tris, float4* __restrict__ out) {
+    const uint2 ch = chunks[blockIdx.x];
+    const DItem& it = items[ch.x];
     if (it.flags & RR_IF_SPHERE) return;
-    for (uint32_t slot = threadIdx.x; slot < it.n_tris; slot += blockDim.x) {
+    const uint32_t end = min(it.n_tris, ch.y + RR_ITEM_CHUNK);
+    for (uint32_t slot = ch.y + threadIdx.x; slot < end; slot += blockDim.x) {
         const float4 v3 = tris[it.tri_base + slot].v3;
         const f3 ng = mk3(v3.x, v3.y, v3.z);
         const f3 p = to_world_normal(it, ng), m = to_world_normal(it, -ng);
@@ -2076,10 +2080,11 @@ __global__ __launch_bounds__(RR_BLOCK) void k_world_normals(const DItem* __restr
 // without contraction and minimum / maximum are exact, so the host evaluation this replaces (one thread, every vertex of every
 // item, three passes: a transform update of sponza_syn spent its time there) gives the same numbers.  A non-finite vertex makes a
 // span non-finite; the host then keeps the box of the local box's corners for that item.
-// out[9 * item + (0..2)] = minima, (3..5) = maxima, (6..8) = largest |coordinate|; spheres and empty meshes: +inf / -inf / 0.
-__global__ __launch_bounds__(RR_BLOCK) void k_item_spans(const DItem* __restrict__ items, uint32_t n_items, const DTri* __restrict__ tris, double* __restrict__ out) {
-    if (blockIdx.x >= n_items) return;
-    const DItem& it = items[blockIdx.x];
+// One workgroup per chunk of an item's triangles, as k_world_normals; the host takes the minimum / maximum over an item's chunks.
+// out[9 * chunk + (0..2)] = minima, (3..5) = maxima, (6..8) = largest |coordinate|; spheres and empty meshes: +inf / -inf / 0.
+__global__ __launch_bounds__(RR_BLOCK) void k_item_spans(const DItem* __restrict__ items, const uint2* __restrict__ chunks, const DTri* __restrict__ tris, double* __restrict__ out) {
+    const uint2 ch = chunks[blockIdx.x];
+    const DItem& it = items[ch.x];
     const bool mesh = !(it.flags & RR_IF_SPHERE);
     const double inf = __builtin_inf();
     double lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf}, ext[3] = {0.0, 0.0, 0.0};
@@ -2087,7 +2092,8 @@ __global__ __launch_bounds__(RR_BLOCK) void k_item_spans(const DItem* __restrict
     if (mesh) {
         const double m[3][3] = {{(double)it.tr0.x, (double)it.tr0.y, (double)it.tr0.z}, {(double)it.tr1.x, (double)it.tr1.y, (double)it.tr1.z},
                                 {(double)it.tr2.x, (double)it.tr2.y, (double)it.tr2.z}};
-        for (uint32_t slot = threadIdx.x; slot < it.n_tris; slot += RR_BLOCK) {
+        const uint32_t end = min(it.n_tris, ch.y + RR_ITEM_CHUNK);
+        for (uint32_t slot = ch.y + threadIdx.x; slot < end; slot += RR_BLOCK) {
             const DTri& t = tris[it.tri_base + slot];
             const float4 vs[3] = {t.v0, t.v1, t.v2};
 #pragma unroll

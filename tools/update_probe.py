@@ -10,6 +10,9 @@ import numpy as np
 import bench
 from rustray_amd import capi
 
+if os.environ.get("RR_PROBE_ABI"):   # an older library (tools/build_rev.sh): speak its ABI version
+    import rustray_amd.flat as _flat
+    _flat.RR_ABI_VERSION = int(os.environ["RR_PROBE_ABI"])
 scene = sys.argv[1] if len(sys.argv) > 1 else "sponza_syn"
 fs, cam, cfg = bench.build_workload(scene, 1280, 720, 1, 1)
 t = np.stack([np.asarray(it.trans, np.float32) for it in fs.items])
