@@ -265,6 +265,23 @@ def extras(args, ds, camc, cfg, step, fence):
     for k in range(6):
         t0 = time.perf_counter(); ds.pick(camc, args.width // 2 + k, args.height // 2); ts.append((time.perf_counter() - t0) * 1000.0)
     out["pick_ms"] = statistics.median(ts[1:])
+    # an animation on the resident scene (the frame loop of src/run.rs:421-465: apply_frame -> restart -> wait): 8 frames, every item turned a
+    # little further about y each frame (rr_scene_update_transforms), the contract frame rendered after each step
+    def roty(a):
+        c, s_ = np.float32(np.cos(a)), np.float32(np.sin(a))
+        return np.asarray([[c, 0, s_, 0], [0, 1, 0, 0], [-s_, 0, c, 0], [0, 0, 0, 1]], np.float32)
+    n_frames = 8
+    step(); fence()
+    t0 = time.perf_counter()
+    for f in range(1, n_frames + 1):
+        r = roty(0.02 * f)
+        ds.update_transforms((t @ r).astype(np.float32), (r.T @ ti).astype(np.float32))
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ds.update_transforms(t, ti)   # back to the scene as it was
+    out["animation"] = {"frames": n_frames, "frames_per_s": n_frames / dt, "ms_per_frame": dt * 1000.0 / n_frames,
+                        "what": "rr_scene_update_transforms (all items turned about y) + the contract frame, per frame, on the resident scene"}
     # every other BASELINE config at its own size and sample count, one frame each (C1 spheres, C2 monkey, C3 / C5 stand-ins)
     other = {}
     for scene, w, h, spp, mc in (("spheres", 256, 256, 1, 0), ("monkey", 800, 600, 16, 1), ("helmet_syn", args.width, args.height, 64, 1), ("lotus_syn", args.width, args.height, 512, 1)):

@@ -609,6 +609,27 @@ static int build_tlas(rr_scene* s, const double want_reach[3], std::vector<DNode
     int pending = 0;
     *root4 = rr::collapse_bvh4(r, s->tlas_depth_limit, false, tlas4, &pending);
     if (pending > s->tlas_depth_limit) return fail(RR_ERR_UNSUPPORTED, "top level: BVH4 stack bound exceeded");
+    // Balls before meshes among the children of a node.  A walk takes the children of a node nearest box first and, at equal entry
+    // distance, in slot order -- and equal is the rule where it matters: a ray that starts inside an environment sphere AND inside an
+    // object's box (every secondary ray of such a scene) enters both at distance 0.  A ball is decided by a dozen instructions and
+    // its toi then bounds the mesh walk that follows (closest_item passes the best hit so far down); the other way round the mesh is
+    // walked without a bound first.  helmet_syn's secondary rays all end on its solid environment sphere at toi 0: with the sphere
+    // in front, the walk of the 80 k-triangle mesh ends at its root.  The candidate SET and the result do not depend on the order.
+    for (DNode4& nd : *tlas4) {
+        int32_t code[4];
+        memcpy(code, &nd.q[6], 16);
+        auto is_ball = [&](int k) { return code[k] < 0 && code[k] != (int32_t)0x80000000 && (s->h_items[RR_LEAF_FIRST((uint32_t)~code[k])].flags & RR_IF_SPHERE) != 0u; };
+        int order[4], m = 0;
+        for (int k = 0; k < 4; k++) if (is_ball(k)) order[m++] = k;
+        if (m == 0) continue;
+        for (int k = 0; k < 4; k++) if (!is_ball(k) && code[k] != (int32_t)0x80000000) order[m++] = k;
+        for (int k = 0; k < 4; k++) if (code[k] == (int32_t)0x80000000) order[m++] = k;
+        DNode4 src = nd;
+        for (int r = 0; r < 7; r++) {
+            const float v[4] = {src.q[r].x, src.q[r].y, src.q[r].z, src.q[r].w};
+            nd.q[r] = make_float4(v[order[0]], v[order[1]], v[order[2]], v[order[3]]);
+        }
+    }
     return RR_OK;
 }
 

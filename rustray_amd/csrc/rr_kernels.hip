@@ -442,60 +442,6 @@ struct TriBest { float t; uint32_t slot; uint32_t face; uint32_t side; bool foun
         }                                                                                                      \
     }
 #endif
-// The same with the NON-uniform leaves tested in ROUNDS (RR_LEAF_ROUNDS): a parked lane tests RR_LEAF_ROUNDS triangles of its leaf per
-// round and stays parked while triangles are left, instead of every lane looping over its whole leaf while the lanes with shorter
-// leaves idle (leaves hold 1 .. 8 triangles).  `pi`: the lane's next triangle within its parked leaf.
-#define RR_LEAF_CLOSEST_ROUND(leaf, pi)                                                                        \
-    {                                                                                                          \
-        const int uleaf_ = __builtin_amdgcn_readfirstlane(leaf);                                               \
-        const uint32_t utri_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)tri_base_);                       \
-        if (SCALAR_LEAVES && sr.uni && __ballot((leaf) != uleaf_ || tri_base_ != utri_ || (pi) != 0u) == 0ull) { \
-            const uint32_t ucode = (uint32_t)~uleaf_;                                                          \
-            const uint32_t ufirst = RR_LEAF_FIRST(ucode), ucount = RR_LEAF_COUNT(ucode);                       \
-            const uint32_t ubase = utri_ + ufirst;                                                             \
-            for (uint32_t i = 0; i < ucount; i += 2u) {                                                        \
-                RR_UTIL(3)                                                                                     \
-                const bool two_ = i + 1u < ucount;                                                             \
-                const uint32_t o0 = (ubase + i) * 48u, o1 = (ubase + i + (two_ ? 1u : 0u)) * 48u;              \
-                DTriX ta, tb;                                                                                  \
-                RR_TRI_FETCH(ta, o0) RR_TRI_FETCH(tb, o1)                                                      \
-                RR_TRI_CLOSEST(ta, ufirst + i)                                                                 \
-                if (two_) RR_TRI_CLOSEST(tb, ufirst + i + 1u)                                                  \
-            }                                                                                                  \
-            (leaf) = 0;                                                                                        \
-        } else {                                                                                               \
-            const uint32_t code = (uint32_t)~(leaf);                                                           \
-            const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);                           \
-            _Pragma("unroll") for (int r_ = 0; r_ < RR_LEAF_ROUNDS; r_++) {                                    \
-                if ((pi) < count) {                                                                            \
-                    RR_UTIL(3) RR_UTIL_UNI(3, tri_base_ + first + (pi), 0)                                     \
-                    const DTriX tr = tri_at(sc.trix, (tri_base_ + first + (pi)) * 48u);                        \
-                    RR_TRI_CLOSEST(tr, first + (pi))                                                           \
-                    (pi)++;                                                                                    \
-                }                                                                                              \
-            }                                                                                                  \
-            if ((pi) >= count) (leaf) = 0;                                                                     \
-        }                                                                                                      \
-    }
-#define RR_LEAF_ANY_ROUND(leaf, pi)                                                                            \
-    {                                                                                                          \
-        const uint32_t code = (uint32_t)~(leaf);                                                               \
-        const uint32_t first = RR_LEAF_FIRST(code), count = RR_LEAF_COUNT(code);                               \
-        _Pragma("unroll") for (int r_ = 0; r_ < RR_LEAF_ROUNDS; r_++) {                                        \
-            if ((pi) < count) {                                                                                \
-                RR_UTIL(3) RR_UTIL_UNI(3, tri_base_ + first + (pi), 0)                                         \
-                const DTriX tr = tri_at(sc.trix, (tri_base_ + first + (pi)) * 48u);                            \
-                float t; uint32_t side;                                                                        \
-                if (ray_triangle(mk3(tr.t0.x, tr.t0.y, tr.t0.z), mk3(tr.t1.x, tr.t1.y, tr.t1.z),               \
-                                 mk3(tr.t1.w, tr.t2.x, tr.t2.y), ray, &t, &side)) {                            \
-                    any = true;                                                                                \
-                    if (t <= limit) within = true;                                                             \
-                }                                                                                              \
-                (pi)++;                                                                                        \
-            }                                                                                                  \
-        }                                                                                                      \
-        if ((pi) >= count) (leaf) = 0;                                                                         \
-    }
 #define RR_LEAF_ANY(leaf)                                                                                      \
     {                                                                                                          \
         const uint32_t code = (uint32_t)~(leaf);                                                               \
@@ -525,28 +471,18 @@ RR_DEV void blas_closest(const DSceneView& sc, const DItem& it, const LRay& ray,
     int cur = RR_BLAS_ROOT(it);
     RR_UTIL(4)
     int pend = 0; // parked leaf (leaf codes are negative), 0 = none
-#ifdef RR_LEAF_ROUNDS
-    uint32_t pi = 0u; // next triangle of the parked leaf
-#endif
     for (;;) {
         if (cur >= 0) {
             RR_BLAS_STEP(nodes, sr, fminf(gbound, best.t))
         } else if (pend == 0 && cur != RR_SENTINEL) {
             pend = cur; sp--; cur = STK(sp);
-#ifdef RR_LEAF_ROUNDS
-            pi = 0u;
-#endif
         }
         const unsigned long long can_walk = __ballot(cur >= 0 || (pend == 0 && cur != RR_SENTINEL));
         const unsigned long long parked = __ballot(pend != 0);
         if ((can_walk | parked) == 0ull) break; // every lane of this walk is done
         const unsigned long long alive = __ballot(cur != RR_SENTINEL || pend != 0);
         if (can_walk == 0ull || __popcll(parked) * RR_PEND_DEN >= __popcll(alive) * RR_PEND_NUM) {
-#ifdef RR_LEAF_ROUNDS
-            if (pend != 0) { RR_LEAF_CLOSEST_ROUND(pend, pi) }
-#else
             if (pend != 0) { RR_LEAF_CLOSEST(pend) pend = 0; }
-#endif
         }
     }
     *out = best;
@@ -566,17 +502,11 @@ RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, flo
     RR_UTIL(4)
     // until some hit is known every box matters; afterwards only boxes that can still hold a hit within the limit
     int pend = 0;
-#ifdef RR_LEAF_ROUNDS
-    uint32_t pi = 0u;
-#endif
     for (;;) {
         if (cur >= 0) {
             RR_BLAS_STEP_ANY(nodes, sr, any ? limit : RR_FLT_MAX)
         } else if (pend == 0 && cur != RR_SENTINEL) {
             pend = cur; sp--; cur = STK(sp);
-#ifdef RR_LEAF_ROUNDS
-            pi = 0u;
-#endif
         }
         const unsigned long long can_walk = __ballot(cur >= 0 || (pend == 0 && cur != RR_SENTINEL));
         const unsigned long long parked = __ballot(pend != 0);
@@ -584,14 +514,9 @@ RR_DEV void blas_any(const DSceneView& sc, const DItem& it, const LRay& ray, flo
         const unsigned long long alive = __ballot(cur != RR_SENTINEL || pend != 0);
         if (can_walk == 0ull || __popcll(parked) * RR_PEND_DEN >= __popcll(alive) * RR_PEND_NUM) {
             if (pend != 0) {
-#ifdef RR_LEAF_ROUNDS
-                RR_LEAF_ANY_ROUND(pend, pi)
-                if (within) { cur = RR_SENTINEL; pend = 0; } // decided: this lane stops walking
-#else
                 RR_LEAF_ANY(pend)
                 pend = 0;
                 if (within) cur = RR_SENTINEL; // decided: this lane stops walking
-#endif
             }
         }
     }

@@ -18,7 +18,7 @@ scene = sys.argv[4] if len(sys.argv) > 4 else "sponza_syn"
 sfx = "" if scene == "sponza_syn" else "_" + scene   # the headline workload keeps the names bench.py looks for
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
-KERNELS = ("k_trace_closest", "k_trace_closest<true>", "k_trace_closest<false>", "k_trace_shadow", "k_trace_shadow<true>", "k_trace_shadow<false>", "k_shade", "k_shade<true>", "k_shade<false>", "k_resolve")
+KERNELS = ("k_trace_closest", "k_trace_closest<true>", "k_trace_closest<false>", "k_stream_prepare", "k_stream_walk", "k_trace_shadow", "k_trace_shadow<true>", "k_trace_shadow<false>", "k_shade", "k_shade<true>", "k_shade<false>", "k_resolve")
 
 
 def kname(raw):
