@@ -544,14 +544,13 @@ static void padded_world_box(const DItem& it, const WorldBox& b, const double re
 
 // Builds the top-level tree over s->h_items for ray origins within +-reach (grown to cover the items themselves: the
 // origins of secondary and shadow rays lie on them).
-static int build_tlas(rr_scene* s, const double want_reach[3], std::vector<DNode4>* tlas4, int32_t* root4) {
+struct TlasTrees { std::vector<DNode4> corner, surface; int32_t root = (int32_t)0x80000000, root_surface = (int32_t)0x80000000; bool has_surface = false; };
+static int tlas_tree(rr_scene* s, const float* lo, const float* hi, uint32_t n, std::vector<DNode4>* tlas4, int32_t* root4);
+static int build_tlas(rr_scene* s, const double want_reach[3], TlasTrees* trees) {
     uint32_t n = (uint32_t)s->h_items.size();
-    tlas4->clear();
+    *trees = TlasTrees();
     for (int c = 0; c < 3; c++) s->tlas_reach[c] = want_reach[c];
-    if (n == 0) { // empty scene: every walk ends at once
-        *root4 = (int32_t)0x80000000; // RR_SENTINEL
-        return RR_OK;
-    }
+    if (n == 0) return RR_OK; // empty scene: every walk ends at once (both roots RR_SENTINEL)
     // two boxes per item: the box of its local box's corners -- what the tree is built over and what shadow packets are tested against:
     // the shadow query orders items by the distance at which the LOCAL box is entered, and prunes by it, which only a world box that
     // contains the local box bounds from below -- and the box of its surface (exact_world_box), which the closest-hit packets use:
@@ -593,8 +592,32 @@ static int build_tlas(rr_scene* s, const double want_reach[3], std::vector<DNode
         s->h_item_boxes[2 * ((size_t)n + i)] = make_float4(tl[0], tl[1], tl[2], 0.0f);
         s->h_item_boxes[2 * ((size_t)n + i) + 1] = make_float4(th[0], th[1], th[2], 0.0f);
     }
+    int rc = tlas_tree(s, lo.data(), hi.data(), n, &trees->corner, &trees->root);
+    if (rc != RR_OK) return rc;
+    // The per-ray closest-hit walks get a tree of their own over the SURFACE boxes (the argument above holds for any closest-hit query: an
+    // item matters through its nearest hit alone; until round 4 only the packet form used them): fewer items are set up per ray and fewer
+    // mesh walks entered.  Shadow queries keep the tree over the corner boxes (their order is the local boxes' entry distance).
+    bool differs = false;
+    for (size_t k = 0; k < 2 * (size_t)n && !differs; k++)
+        differs = memcmp(&s->h_item_boxes[k], &s->h_item_boxes[2 * (size_t)n + k], sizeof(float4)) != 0;
+    trees->has_surface = differs;
+    if (differs) {
+        for (uint32_t i = 0; i < n; i++) {
+            const float4 tl = s->h_item_boxes[2 * ((size_t)n + i)], th = s->h_item_boxes[2 * ((size_t)n + i) + 1];
+            lo[3 * (size_t)i] = tl.x; lo[3 * (size_t)i + 1] = tl.y; lo[3 * (size_t)i + 2] = tl.z;
+            hi[3 * (size_t)i] = th.x; hi[3 * (size_t)i + 1] = th.y; hi[3 * (size_t)i + 2] = th.z;
+        }
+        rc = tlas_tree(s, lo.data(), hi.data(), n, &trees->surface, &trees->root_surface);
+        if (rc != RR_OK) return rc;
+    }
+    return RR_OK;
+}
+
+// One top-level tree over the items' boxes lo / hi (n * 3 floats): binned SAH, one item per leaf, collapsed to 4-wide nodes.
+static int tlas_tree(rr_scene* s, const float* lo, const float* hi, uint32_t n, std::vector<DNode4>* tlas4, int32_t* root4) {
+    tlas4->clear();
     rr::BvhResult r;
-    if (!rr::build_bvh(lo.data(), hi.data(), n, 1, s->tlas_depth_limit, &r))
+    if (!rr::build_bvh(lo, hi, n, 1, s->tlas_depth_limit, &r))
         return fail(RR_ERR_UNSUPPORTED, "internal: top level over %u items does not fit %d levels", n, s->tlas_depth_limit);
     // leaves must name item indices directly: leaf order is a permutation, so re-code each 1-item leaf
     for (DNode& nd : r.nodes) {
@@ -633,6 +656,20 @@ static int build_tlas(rr_scene* s, const double want_reach[3], std::vector<DNode
     return RR_OK;
 }
 
+// The two trees into the scene's node buffer (the corner tree in its first half, the surface tree in the second: tlas_node_capacity
+// nodes each), the item boxes, and the roots into the view.  Blocking copies.
+static int upload_tlas(rr_scene* s, const TlasTrees& t) {
+    if (t.corner.size() > s->tlas_node_capacity || t.surface.size() > s->tlas_node_capacity)
+        return fail(RR_ERR_DEVICE, "top-level rebuild needs %zu / %zu nodes, capacity %u", t.corner.size(), t.surface.size(), s->tlas_node_capacity);
+    if (!t.corner.empty()) HIP_TRY(hipMemcpy(s->tnodes4.p, t.corner.data(), t.corner.size() * sizeof(DNode4), hipMemcpyHostToDevice));
+    if (!t.surface.empty()) HIP_TRY(hipMemcpy(s->tnodes4.as<DNode4>() + s->tlas_node_capacity, t.surface.data(), t.surface.size() * sizeof(DNode4), hipMemcpyHostToDevice));
+    if (!s->h_item_boxes.empty()) HIP_TRY(hipMemcpy(s->item_boxes.p, s->h_item_boxes.data(), s->h_item_boxes.size() * sizeof(float4), hipMemcpyHostToDevice));
+    s->view.tlas_root4 = t.root;
+    s->view.tnodes4c = t.has_surface ? s->tnodes4.as<DNode4>() + s->tlas_node_capacity : s->tnodes4.as<DNode4>();
+    s->view.tlas_root4c = t.has_surface ? t.root_surface : t.root;
+    return RR_OK;
+}
+
 // Ray origins of the coming launch reach out to +-need: rebuilds the top level when its boxes were padded for less
 // (a camera far outside the scene), or for more than 16x as much (the camera came back).
 static int ensure_tlas_reach(rr_scene* s, const double need[3]) {
@@ -644,16 +681,11 @@ static int ensure_tlas_reach(rr_scene* s, const double need[3]) {
     if (!grow && !shrink) return RR_OK;
     double want[3];
     for (int c = 0; c < 3; c++) want[c] = 2.0 * need[c]; // build_tlas raises it to the items' own extent
-    std::vector<DNode4> tlas4; int32_t root4 = 0;
-    int rc = build_tlas(s, want, &tlas4, &root4);
+    TlasTrees trees;
+    int rc = build_tlas(s, want, &trees);
     if (rc != RR_OK) return rc;
-    if (tlas4.size() > s->tlas_node_capacity)
-        return fail(RR_ERR_DEVICE, "top-level rebuild needs %zu nodes, capacity %u", tlas4.size(), s->tlas_node_capacity);
     HIP_TRY(hipDeviceSynchronize());
-    if (!tlas4.empty()) HIP_TRY(hipMemcpy(s->tnodes4.p, tlas4.data(), tlas4.size() * sizeof(DNode4), hipMemcpyHostToDevice));
-    if (!s->h_item_boxes.empty()) HIP_TRY(hipMemcpy(s->item_boxes.p, s->h_item_boxes.data(), s->h_item_boxes.size() * sizeof(float4), hipMemcpyHostToDevice));
-    s->view.tlas_root4 = root4;
-    return RR_OK;
+    return upload_tlas(s, trees);
 }
 // bound on the primary-ray origins of a camera (primary_ray: view_inv * (proj_inv * (sx, sy, -1, 1)).xyz1, |sx|, |sy| <= smax)
 static void camera_reach(const rr_camera* cam, const rr_config* cfg, double need[3]) {
@@ -990,18 +1022,20 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     // ---- top level: always present (even for one item), so the kernels have a single traversal path.
     // The reference's choice between "all items" and its scene BVH (src/raytracing.rs:434) only changes the
     // candidate set, never the result.
-    std::vector<DNode4> tlas4;
-    int32_t tlas_root4 = (int32_t)0x80000000; // RR_SENTINEL: empty scene
     {
+        TlasTrees trees;
         const double none[3] = {0.0, 0.0, 0.0};
-        rc = build_tlas(s.get(), none, &tlas4, &tlas_root4);
+        rc = build_tlas(s.get(), none, &trees);
         if (rc != RR_OK) return rc;
         for (int c = 0; c < 3; c++) s->tlas_floor[c] = s->tlas_reach[c];
+        s->tlas_node_capacity = std::max<uint32_t>((uint32_t)std::max(trees.corner.size(), trees.surface.size()), fs->n_items ? fs->n_items : 1u); // room for rebuilds after transform updates
+        HIP_TRY(s->tnodes4.reserve(2 * (size_t)s->tlas_node_capacity * sizeof(DNode4)));
+        HIP_TRY(hipMemset(s->tnodes4.p, 0, 2 * (size_t)s->tlas_node_capacity * sizeof(DNode4)));
+        HIP_TRY(s->item_boxes.reserve(std::max<size_t>(s->h_item_boxes.size() * sizeof(float4), 16)));
+        s->view.tnodes4 = s->tnodes4.as<DNode4>();
+        rc = upload_tlas(s.get(), trees);
+        if (rc != RR_OK) return rc;
     }
-    s->tlas_node_capacity = std::max<uint32_t>((uint32_t)tlas4.size(), fs->n_items ? fs->n_items : 1u); // room for rebuilds after transform updates
-    tlas4.resize(std::max<size_t>(tlas4.size(), s->tlas_node_capacity));
-    HIP_TRY(upload(s->tnodes4, tlas4.data(), tlas4.size() * sizeof(DNode4)));
-    HIP_TRY(upload(s->item_boxes, s->h_item_boxes.data(), s->h_item_boxes.size() * sizeof(float4)));
 
     DSceneView& v = s->view;
     v.flat_normals = s->flat_normals.as<float4>();
@@ -1011,7 +1045,7 @@ extern "C" int rr_scene_create(const rr_flat_scene* fs, int device, rr_scene** o
     v.lights = s->lights.as<DLight>();
     v.n_items = fs->n_items; v.n_lights = fs->n_lights; v.n_enabled_lights = s->n_enabled_lights;
     v.item_boxes = s->item_boxes.as<float4>();
-    v.tnodes4 = s->tnodes4.as<DNode4>(); v.tlas_root4 = tlas_root4; v.general_w = general_w ? 1u : 0u;
+    v.general_w = general_w ? 1u : 0u;
 
     HIP_TRY(s->pool.reserve(POOL_WORDS * 4));
     HIP_TRY(s->counters.reserve(RR_CNT_WORDS * 8));
@@ -1050,16 +1084,13 @@ extern "C" int rr_scene_update_transforms(rr_scene* s, const float* trans, const
     { int rc = derive_from_transforms(s); if (rc != RR_OK) return rc; }
     s->view.general_w = general_w ? 1u : 0u;
     {
-        std::vector<DNode4> tlas4; int32_t root4 = 0;
+        TlasTrees trees;
         const double none[3] = {0.0, 0.0, 0.0};
-        int rc = build_tlas(s, none, &tlas4, &root4); // the next frame's camera grows the reach again if it has to
+        int rc = build_tlas(s, none, &trees); // the next frame's camera grows the reach again if it has to
         if (rc != RR_OK) return rc;
         for (int c = 0; c < 3; c++) s->tlas_floor[c] = s->tlas_reach[c];
-        if (tlas4.size() > s->tlas_node_capacity)
-            return fail(RR_ERR_DEVICE, "top-level rebuild needs %zu nodes, capacity %u", tlas4.size(), s->tlas_node_capacity);
-        if (!tlas4.empty()) HIP_TRY(hipMemcpy(s->tnodes4.p, tlas4.data(), tlas4.size() * sizeof(DNode4), hipMemcpyHostToDevice));
-        if (!s->h_item_boxes.empty()) HIP_TRY(hipMemcpy(s->item_boxes.p, s->h_item_boxes.data(), s->h_item_boxes.size() * sizeof(float4), hipMemcpyHostToDevice));
-        s->view.tlas_root4 = root4;
+        rc = upload_tlas(s, trees);
+        if (rc != RR_OK) return rc;
     }
     return RR_OK;
 } RR_GUARD_END("rr_scene_update_transforms")

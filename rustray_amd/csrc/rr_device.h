@@ -137,6 +137,8 @@ struct DSceneView {
     uint32_t n_enabled_lights; // any number; level 1 uses fixed shadow slots for up to RR_FIXED_SLOT_LIGHTS of them
     const DNode4* tnodes4;  // the top level over item world boxes, same form (one item per leaf)
     int32_t tlas_root4;      // node index, a leaf code (one item), or RR_SENTINEL (empty scene)
+    const DNode4* tnodes4c;  // the top level of the per-ray CLOSEST-HIT walks: over the items' surface boxes where those are tighter (rr_api.hip build_tlas),
+    int32_t tlas_root4c;     // else the same tree as tnodes4 / tlas_root4 (which shadow queries always take)
     const float4* item_boxes; // padded world boxes per item for the packet form of the top level: [2 i] = lo, [2 i + 1] = hi of the item's corner box (the boxes of
                               // the tree; trace_shadow_packet), [2 (n_items + i)], [.. + 1] of its surface box (trace_closest_packet); rr_api.hip build_tlas
     uint32_t any_alpha_occluder; // some item's material has an alpha map: the shadow attenuation of a receiver whose uv may be NaN can be NaN (k_shade, want_shadow)

@@ -189,7 +189,7 @@ __shared__ uint32_t s_util_kind; // 0: closest-hit level 1, 1: closest-hit deepe
 #define RR_UTIL(slot) { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63u) == __ffsll((long long)m_) - 1) { \
         atomicAdd(&g_util[10 * s_util_kind + 2 * (slot)], (unsigned long long)__popcll(m_)); atomicAdd(&g_util[10 * s_util_kind + 2 * (slot) + 1], 1ull); } }
 #define RR_UTIL_KIND(k) { s_util_kind = (k); __syncthreads(); }
-#define RR_UTIL_NODE_SLOT ((const void*)nodes4_ptr_ == (const void*)sc.tnodes4 ? 0 : 2)
+#define RR_UTIL_NODE_SLOT (((const void*)nodes4_ptr_ == (const void*)sc.tnodes4 || (const void*)nodes4_ptr_ == (const void*)sc.tnodes4c) ? 0 : 2)
 // steps whose address is the same in every active lane (g_util[30 + ...]: [0] same address, [1] same address and same key2)
 #define RR_UTIL_UNI(slot, addr, key2) { const unsigned long long m_ = __ballot(1); const int l_ = __ffsll((long long)m_) - 1;                \
         const uint32_t a_ = (uint32_t)(addr), k_ = (uint32_t)(key2); const uint32_t ua_ = __shfl(a_, l_), uk_ = __shfl(k_, l_);               \
@@ -770,11 +770,11 @@ RR_DEV void trace_closest_ray(const DSceneView& sc, f3 o, f3 d, uint32_t depth, 
     const Slab4 ws = make_slab4(make_slab(o, d), 0u);
     int sp = 1;
     STK(0) = RR_SENTINEL;
-    int cur = sc.tlas_root4;
+    int cur = sc.tlas_root4c; // (the closest-hit tree: surface boxes)
     // while-while: every lane walks the top level until it holds a candidate item (or is done), so the per-mesh
     // walks below run with the lanes of the wave together instead of one straggler at a time
     for (;;) {
-        while (cur >= 0) { RR_NODE4_STEP(sc.tnodes4, ws, fminf(best->t * RR_TOI_SLACK, RR_FLT_MAX)) }
+        while (cur >= 0) { RR_NODE4_STEP(sc.tnodes4c, ws, fminf(best->t * RR_TOI_SLACK, RR_FLT_MAX)) }
         if (cur == RR_SENTINEL) break;
         closest_item(sc, (int)RR_LEAF_FIRST((uint32_t)~cur), o, d, depth, s_stack, sp, best); // one item per top-level leaf
         sp--; cur = STK(sp);
