@@ -378,6 +378,16 @@ int rr_render_progressive(rr_scene* scene, const rr_camera* camera, const rr_con
                           const uint16_t* sample_xy, const rr_frame* out, uint32_t min_passes,
                           rr_pass_fn on_pass, void* user, const volatile int* cancel);
 
+/* The frame filled in TILE BY TILE instead: every pixel is final when it appears, as in the reference's GUI (shuffled 2x2-pixel cells, each
+ * rendered with all of its samples: src/renderer.rs:125-172).  Pass k of n_passes (0 = 16; at most the number of tiles) renders the 32x8-pixel
+ * tiles with (tile_index % n_passes == k), an interleaved subset of the frame, and after each pass but the last the host buffers of `out` hold the
+ * frame so far (pixels not rendered yet are zero) and `on_pass(user, samples_done, samples_total)` is called on the calling thread; a non-zero
+ * return stops the frame (RR_ERR_CANCELLED, `out` keeps what was finished).  The finished frame is bit-identical to rr_render's;
+ * rr_scene_last_stats reports the sums over the passes. */
+int rr_render_progressive_tiles(rr_scene* scene, const rr_camera* camera, const rr_config* config,
+                                const uint16_t* sample_xy, const rr_frame* out, uint32_t n_passes,
+                                rr_pass_fn on_pass, void* user, const volatile int* cancel);
+
 /* Number of pixels `region` owns in a width x height frame. */
 uint64_t rr_region_pixel_count(uint32_t width, uint32_t height, const rr_region* region);
 

@@ -21,7 +21,7 @@ _LIB = None
 # every symbol include/rustray_hip.h declares (tests/test_abi.py checks the list against the header)
 EXPORTS = ["rr_abi_version", "rr_device_count", "rr_last_error", "rr_scene_create", "rr_scene_destroy", "rr_scene_update_transforms",
            "rr_scene_update_materials", "rr_scene_set_tuning", "rr_scene_get_tuning", "rr_scene_set_compat",
-           "rr_sample_table", "rr_render", "rr_render_multi", "rr_multi_lock_order", "rr_render_progressive", "rr_region_pixel_count", "rr_render_region_device",
+           "rr_sample_table", "rr_render", "rr_render_multi", "rr_multi_lock_order", "rr_render_progressive", "rr_render_progressive_tiles", "rr_region_pixel_count", "rr_render_region_device",
            "rr_deinterleave_device", "rr_deinterleave_packed_device", "rr_pick", "rr_trace_rays", "rr_scene_last_stats", "rr_post_process", "rr_post_process_device"]
 
 
@@ -81,6 +81,8 @@ def lib():
         L.rr_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p, C.POINTER(rr_frame), C.c_void_p]
         L.rr_render_progressive.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p, C.POINTER(rr_frame),
                                             C.c_uint32, PASS_FN, C.c_void_p, C.c_void_p]
+        L.rr_render_progressive_tiles.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p, C.POINTER(rr_frame),
+                                                  C.c_uint32, PASS_FN, C.c_void_p, C.c_void_p]
         L.rr_render_region_device.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p,
                                               C.POINTER(rr_region), C.POINTER(rr_frame), C.c_void_p, C.c_void_p]
         L.rr_deinterleave_device.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -170,9 +172,10 @@ class DeviceScene:
         _check(lib().rr_render(self._h, C.byref(cam), C.byref(cfg), p, C.byref(fr), None))
         return out
 
-    def render_progressive(self, cam: rr_camera, cfg: rr_config, on_pass, min_passes: int = 8, sample_xy=None, aux: bool = True):
+    def render_progressive(self, cam: rr_camera, cfg: rr_config, on_pass, min_passes: int = 8, sample_xy=None, aux: bool = True, tiles: bool = False):
         """rr_render_progressive: `on_pass(out, samples_done, samples_total)` sees the frame resolved over the samples
-        finished so far after every device batch; a truthy return stops the frame (RustrayHipError, code -6)."""
+        finished so far after every device batch; a truthy return stops the frame (RustrayHipError, code -6).
+        tiles=True: rr_render_progressive_tiles -- `min_passes` passes of interleaved 32x8 tiles, every pixel final when it appears."""
         w, h = cam.width, cam.height
         rgba = np.zeros((h, w, 4), np.uint8)
         out = dict(rgba=rgba)
@@ -192,7 +195,8 @@ class DeviceScene:
                 errors.append(e)
                 return 1
         cb = PASS_FN(_cb)
-        rc = lib().rr_render_progressive(self._h, C.byref(cam), C.byref(cfg), p, C.byref(fr), int(min_passes), cb, None, None)
+        fn = lib().rr_render_progressive_tiles if tiles else lib().rr_render_progressive
+        rc = fn(self._h, C.byref(cam), C.byref(cfg), p, C.byref(fr), int(min_passes), cb, None, None)
         if errors:
             raise errors[0]
         _check(rc)

@@ -193,6 +193,7 @@ struct rr_scene {
     uint32_t region_w = 0, region_h = 0;
     // stats
     rr_frame_stats stats{};
+    bool stats_final = false; // s->stats already holds the sums over the passes of rr_render_progressive_tiles (nothing to collect from the device)
     bool profiling = false;
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
@@ -1226,6 +1227,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
     const uint32_t npix = (uint32_t)s->h_region_xy.size();
     resolve_timers(s); // launches of an earlier frame nobody asked about must not leak into this frame's stats
     memset(&s->stats, 0, sizeof s->stats);
+    s->stats_final = false;
     if (npix == 0) return RR_OK;
 
     { // the top level's boxes must be padded for this camera's distance from the origin
@@ -1589,11 +1591,18 @@ extern "C" int rr_render_progressive(rr_scene* s, const rr_camera* cam, const rr
     return render_to_host(s, cam, cfg, sample_xy, out, cancel, on_pass, user, min_passes);
 } RR_GUARD_END("rr_render_progressive")
 
+static int collect_stats_locked(rr_scene* s);
 extern "C" int rr_scene_last_stats(const rr_scene* cs, rr_frame_stats* out) try {
     if (!cs || !out) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");
     rr_scene* s = const_cast<rr_scene*>(cs);
     std::lock_guard<std::mutex> lk(s->mu);
     HIP_TRY(hipSetDevice(s->device));
+    if (!s->stats_final) { const int rc = collect_stats_locked(s); if (rc != RR_OK) return rc; }
+    *out = s->stats;
+    return RR_OK;
+} RR_GUARD_END("rr_scene_last_stats")
+// the device counters and launch timers of the frame (or pass) that ran last, into s->stats
+static int collect_stats_locked(rr_scene* s) {
     float ms = 0.0f;
     if (hipEventSynchronize(s->frame_b) == hipSuccess && hipEventElapsedTime(&ms, s->frame_a, s->frame_b) == hipSuccess) s->stats.ms_total = ms;
     resolve_timers(s);
@@ -1601,9 +1610,58 @@ extern "C" int rr_scene_last_stats(const rr_scene* cs, rr_frame_stats* out) try 
     HIP_TRY(hipMemcpy(c, s->counters.p, sizeof c, hipMemcpyDeviceToHost));
     s->stats.primary_rays = c[RR_CNT_PRIMARY]; s->stats.secondary_rays = c[RR_CNT_SECONDARY];
     s->stats.shadow_rays = c[RR_CNT_SHADOW]; s->stats.shaded_hits = c[RR_CNT_SHADED];
-    *out = s->stats;
     return RR_OK;
-} RR_GUARD_END("rr_scene_last_stats")
+}
+
+// The frame filled in TILE BY TILE, every pixel final when it appears: what the reference's GUI shows (shuffled 2x2 cells, each rendered with all of
+// its samples: src/renderer.rs:125-172, drained by Run::apply_pixels, src/run.rs:506-545).  Pass k of n_passes renders the 32x8-pixel tiles with
+// tile_index % n_passes == k -- an interleaved subset, like the shuffled cell list -- straight into their places in the frame.
+extern "C" int rr_render_progressive_tiles(rr_scene* s, const rr_camera* cam, const rr_config* cfg, const uint16_t* sample_xy, const rr_frame* out,
+                                           uint32_t n_passes, rr_pass_fn on_pass, void* user, const volatile int* cancel) try {
+    if (!on_pass) return fail(RR_ERR_INVALID_ARGUMENT, "on_pass is required (use rr_render for a one-shot frame)");
+    int rc = check_frame_args(s, cam, cfg, sample_xy);
+    if (rc != RR_OK) return rc;
+    if (!out || !out->rgba8) return fail(RR_ERR_INVALID_ARGUMENT, "out->rgba8 is required");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIP_TRY(hipSetDevice(s->device));
+    const uint32_t W = cam->width, H = cam->height, TW = 32, TH = 8;
+    const size_t np = (size_t)W * H;
+    const size_t bytes[4] = {np * 4, np * 12, np * 4, np * 4};
+    void* host[4] = {out->rgba8, out->normal, out->depth, out->object_id};
+    rr_frame dev{};
+    void** devp[4] = {(void**)&dev.rgba8, (void**)&dev.normal, (void**)&dev.depth, (void**)&dev.object_id};
+    for (int k = 0; k < 4; k++)
+        if (host[k]) { HIP_TRY(s->tmp_out[k].reserve(bytes[k])); *devp[k] = s->tmp_out[k].p; HIP_TRY(hipMemsetAsync(s->tmp_out[k].p, 0, bytes[k], nullptr)); }
+    const uint32_t n_tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+    const uint32_t P = std::max(1u, std::min(n_passes ? n_passes : 16u, n_tiles));
+    rr_frame_stats sum{};
+    uint64_t done = 0;
+    for (uint32_t k = 0; k < P; k++) {
+        if (cancel && *cancel) return fail(RR_ERR_CANCELLED, "cancelled");
+        const rr_region rg{TW, TH, P, k};
+        rc = render_region_locked(s, cam, cfg, sample_xy, &rg, &dev, true, nullptr, cancel);
+        if (rc != RR_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        rc = collect_stats_locked(s);
+        if (rc != RR_OK) return rc;
+        {   // the frame's statistics are the sums over its passes
+            const rr_frame_stats& a = s->stats;
+            sum.primary_rays += a.primary_rays; sum.secondary_rays += a.secondary_rays; sum.shadow_rays += a.shadow_rays; sum.shaded_hits += a.shaded_hits;
+            sum.ms_total += a.ms_total; sum.ms_trace_closest += a.ms_trace_closest; sum.ms_trace_shadow += a.ms_trace_shadow; sum.ms_shade += a.ms_shade;
+            sum.launches_trace_closest += a.launches_trace_closest; sum.launches_trace_shadow += a.launches_trace_shadow; sum.launches_shade += a.launches_shade;
+            sum.batches += a.batches; sum.sliced_levels += a.sliced_levels; sum.binned_rays += a.binned_rays; sum.ms_binning += a.ms_binning;
+            sum.ms_trace_closest_level1 += a.ms_trace_closest_level1; sum.launches_trace_closest_level1 += a.launches_trace_closest_level1;
+            sum.ms_shade_level1 += a.ms_shade_level1; sum.launches_shade_level1 += a.launches_shade_level1;
+            sum.ms_trace_shadow_level1 += a.ms_trace_shadow_level1; sum.launches_trace_shadow_level1 += a.launches_trace_shadow_level1;
+        }
+        for (int b = 0; b < 4; b++)
+            if (host[b]) HIP_TRY(hipMemcpy(host[b], s->tmp_out[b].p, bytes[b], hipMemcpyDeviceToHost));
+        done += rr_region_pixel_count(W, H, &rg);
+        s->stats = sum; s->stats_final = true;
+        if (k + 1 < P && on_pass(user, done * cfg->samples, (uint64_t)np * cfg->samples) != 0) return fail(RR_ERR_CANCELLED, "stopped by the pass callback");
+    }
+    return RR_OK;
+} RR_GUARD_END("rr_render_progressive_tiles")
 
 extern "C" int rr_scene_set_compat(rr_scene* s, uint32_t flags) try {
     if (!s) return fail(RR_ERR_INVALID_ARGUMENT, "NULL argument");

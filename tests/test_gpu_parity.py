@@ -348,6 +348,44 @@ def test_shadow_blocker_beyond_the_light(hip, oracle):
     assert_parity(out, ref, "blocker beyond the light")
 
 
+def test_progressive_tiles_fill_the_frame_with_final_pixels(hip):
+    """rr_render_progressive_tiles: the reference's own kind of progress (shuffled 2x2 cells, each rendered with all of its samples,
+    src/renderer.rs:125-172): every pass adds an interleaved subset of 32x8 tiles, a pixel that has appeared never changes again, the
+    finished frame and its statistics equal rr_render's, and the callback can stop the frame."""
+    from rustray_amd.renderer import region_pixels
+    fs = load_scene("spheres_room")
+    w, h = 200, 75   # 7 x 10 tiles, the right column and the bottom row clipped
+    cam = camera_for(fs, w, h).c_struct()
+    cfg = make_config(samples=4, monte_carlo=True, seed=4)
+    with hip.DeviceScene(fs, 0) as ds:
+        ref = ds.render(cam, cfg)
+        ref_stats = ds.stats()
+        snaps = []
+
+        def on_pass(out, done, total):
+            snaps.append((done, total, out["rgba"].copy(), out["object_id"].copy()))
+            return False
+        P = 5
+        out = ds.render_progressive(cam, cfg, on_pass, min_passes=P, tiles=True)
+        st = ds.stats()
+        for k in ("rgba", "normal", "depth", "object_id"):
+            assert np.array_equal(out[k], ref[k], equal_nan=True), k
+        for k in ("primary_rays", "secondary_rays", "shadow_rays", "shaded_hits"):
+            assert st[k] == ref_stats[k], k
+        assert len(snaps) == P - 1 and all(t == w * h * 4 for _, t, _, _ in snaps)
+        covered = np.zeros((h, w), bool)
+        for k, (done, _, rgba, ids) in enumerate(snaps):
+            xy = region_pixels(w, h, 32, 8, P, k)
+            covered[xy[:, 1], xy[:, 0]] = True
+            assert done == int(covered.sum()) * 4
+            assert np.array_equal(rgba[covered], ref["rgba"][covered]) and np.array_equal(ids[covered], ref["object_id"][covered])   # final when they appear
+            assert not rgba[~covered].any()                                                                                     # not rendered yet
+        with pytest.raises(hip.RustrayHipError) as e:
+            ds.render_progressive(cam, cfg, lambda out, done, total: True, min_passes=P, tiles=True)
+        assert e.value.code == -6
+        assert np.array_equal(ds.render(cam, cfg)["rgba"], ref["rgba"])
+
+
 def test_progressive_passes_refine_towards_the_one_shot_frame(hip):
     """rr_render_progressive (the reference shows the frame filling in while it renders, src/run.rs:506-545): every pass
     reports more samples, previews are whole frames, the finished frame is bit-identical to rr_render's, and a callback
