@@ -274,7 +274,9 @@ typedef struct rr_frame_stats {
     uint32_t multi_staged_links;  /* handles whose buffers were staged through pinned host memory (no peer access between the devices) */
     uint32_t _pad;
     double ms_multi_exchange;     /* host wall time from the last device finishing its tiles to the frame being in `out` */
-    /* the level-1 share of ms_shade / ms_trace_shadow (the k_shade<true> / k_trace_shadow<true> builds), as ms_trace_closest_level1 (ABI 3) */
+    /* the share of ms_shade / ms_trace_shadow spent in the level-1 BUILDS of those kernels (k_shade<true>; k_trace_shadow<true>: level 1 of a scene
+     * whose shadow rays have fixed slots -- 17 .. 512 items, up to 32 enabled lights -- else 0: level 1 then runs the deeper levels' build), as
+     * ms_trace_closest_level1 (ABI 3) */
     double ms_shade_level1;
     uint64_t launches_shade_level1;
     double ms_trace_shadow_level1;

@@ -1462,7 +1462,7 @@ static int render_region_locked(rr_scene* s, const rr_camera* cam, const rr_conf
                     HIP_TRY(hipEventRecord(s->count_ready, st));
                 }
                 if (L) {
-                    ScopedTimer t(s, st, d == 1 ? 6 : 1);
+                    ScopedTimer t(s, st, sq_fixed ? 6 : 1); // (by kernel BUILD: level 1 of a scene without fixed shadow slots runs k_trace_shadow<false>)
                     if (sq_fixed) {
                         const uint32_t sq_packets = (sq_chunk_cap / RR_WAVE) * L;
                         const int sgrid = (int)std::min<uint64_t>(((uint64_t)sq_packets * RR_WAVE + RR_BLOCK - 1) / RR_BLOCK, (uint64_t)shadow_grid);
