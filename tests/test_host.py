@@ -196,3 +196,55 @@ def test_bench_scene_file_is_real_when_its_assets_are_present_and_the_stand_in_o
     fs, cam, cfg = bench.build_workload("scene/sponza.json", 64, 36, 2, 1, str(tmp_path))
     assert fs.meta["data"] == "synthetic" and fs.name == "sponza_syn" and len(fs.items) > 50
     assert "Sponza_fixed.glb" in capsys.readouterr().err
+
+
+def test_bench_prices_every_kernel_build_and_never_mixes_builds(monkeypatch):
+    """bench.kernel_rooflines: `roofline.kernels` holds every kernel build of the frame with its live time; `frac` is quoted only against
+    SQ counters of the SAME sources and workload (profiles/rNN_sq_counters*.json carry the source_id they were taken on), and the line
+    says why when it is not."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(SCENES))
+    import bench
+    prof = json.load(open(os.path.join(os.path.dirname(SCENES), "profiles", "r04_sq_counters.json")))
+    k1 = prof["kernels"]["k_trace_closest<true>"]
+    acc = dict(primary_rays=3 * 117964800, secondary_rays=3 * 4.5e6, shadow_rays=3e8, shaded_hits=3e8, ms_trace_closest=3 * 6.6, ms_trace_shadow=3 * 6.0, ms_shade=3 * 6.6,
+               launches_trace_closest=6, launches_trace_shadow=9, launches_shade=9, ms_total=58.0, ms_binning=0.0, binned_rays=0,
+               ms_trace_closest_level1=3 * 6.2, launches_trace_closest_level1=3, ms_shade_level1=3 * 6.3, launches_shade_level1=6,
+               ms_trace_shadow_level1=3 * 5.5, launches_trace_shadow_level1=6)
+    roof = bench.kernel_rooflines("sponza_syn", 1280, 720, 128, acc, 3, prof["source_id"])
+    assert roof["kernel"] == "k_trace_closest<true>" and roof["bound"] == "valu_issue" and abs(roof["avg_launch_ms"] - 6.2) < 1e-9
+    assert abs(roof["frac"] - k1["SQ_INSTS_VALU"] / 6.2e-3 / 1e9 / bench.VALU_PEAK_GINST) < 1e-9 and 0.3 < roof["frac"] < 0.6
+    assert set(roof["kernels"]) == {"k_trace_closest<true>", "k_shade<true>", "k_trace_shadow<true>", "k_trace_closest<false>", "k_shade<false>", "k_trace_shadow<false>"}
+    for name, k in roof["kernels"].items():
+        assert k["frac"] is not None and 0.0 < k["frac"] < 1.0 and k["ms_per_frame"] > 0.0, name
+    assert abs(roof["kernels"]["k_trace_shadow<false>"]["ms_per_frame"] - 0.5) < 1e-9 and roof["kernels"]["k_shade<true>"]["launches_per_frame"] == 2
+    # another build of the library: times are still reported, the instruction counts are not borrowed
+    other = bench.kernel_rooflines("sponza_syn", 1280, 720, 128, acc, 3, "0123456789abcdef")
+    assert other["frac"] is None and "re-run tools/profile_round.sh" in other["frac_reason"]
+    assert all(k["frac"] is None and k["ms_per_frame"] > 0.0 for k in other["kernels"].values())
+    # another workload of the same scene, and a scene nobody profiled
+    assert bench.kernel_rooflines("sponza_syn", 640, 360, 128, acc, 3, prof["source_id"])["frac"] is None
+    assert "no profiles" in bench.kernel_rooflines("kbert_room", 1280, 720, 128, acc, 3, prof["source_id"])["frac_reason"]
+    assert bench.kernel_rooflines("sponza_syn", 1280, 720, 128, dict(acc, launches_trace_closest_level1=0), 3, prof["source_id"]) is None
+
+
+def test_bench_waits_for_the_other_ranks_by_pid():
+    """N > 1: before the one-process leg starts, rank 0 waits until the other ranks' processes are gone -- bounded, and the line says
+    what happened (it used to sleep two seconds and hope)."""
+    import subprocess
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(SCENES))
+    import bench
+    p = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(0.6)"])
+    t0 = time.perf_counter()
+    r = bench.wait_for_ranks_to_leave([p.pid], limit_s=10.0)
+    dt = time.perf_counter() - t0
+    p.wait()
+    assert r["ranks_gone"] and r["still_alive"] == [] and 0.3 < dt < 5.0   # a zombie (exited, not yet reaped) counts as gone
+    q = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(5)"])
+    r = bench.wait_for_ranks_to_leave([q.pid], limit_s=0.3)
+    assert not r["ranks_gone"] and r["still_alive"] == [q.pid] and r["waited_s"] < 2.0
+    q.kill(); q.wait()
+    assert bench.wait_for_ranks_to_leave([], limit_s=1.0)["ranks_gone"]
