@@ -81,8 +81,9 @@ def lib():
         L.rr_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p, C.POINTER(rr_frame), C.c_void_p]
         L.rr_render_progressive.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p, C.POINTER(rr_frame),
                                             C.c_uint32, PASS_FN, C.c_void_p, C.c_void_p]
-        L.rr_render_progressive_tiles.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p, C.POINTER(rr_frame),
-                                                  C.c_uint32, PASS_FN, C.c_void_p, C.c_void_p]
+        if hasattr(L, "rr_render_progressive_tiles") or not os.environ.get("RUSTRAY_HIP_LIB"):   # (a developer A/B build of an older revision may lack it)
+            L.rr_render_progressive_tiles.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p, C.POINTER(rr_frame),
+                                                      C.c_uint32, PASS_FN, C.c_void_p, C.c_void_p]
         L.rr_render_region_device.argtypes = [C.c_void_p, C.POINTER(rr_camera), C.POINTER(rr_config), C.c_void_p,
                                               C.POINTER(rr_region), C.POINTER(rr_frame), C.c_void_p, C.c_void_p]
         L.rr_deinterleave_device.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
